@@ -1,0 +1,112 @@
+"""The oracle (oracle/*.py) against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only.  Tolerance: 1e-4 relative on logits/loss/grad
+norms (two implementations on the same ATen CPU ops; far inside the 1e-3 budget that
+BASELINE.json gives the HIP path)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import multigrid_oracle as mo
+from oracle import x3d_oracle as xo
+from x3dhip import synthetic
+from tests import parity
+
+RTOL = 1e-4
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    g = _load(golden_dir, "keys")
+    for v, s in (("M", 1), ("M", 4), ("XL", 2)):
+        sd = xo.state_template(v, 400, s)
+        assert list(sd.keys()) == list(g["keys_%s_%d" % (v, s)])
+        assert ["x".join(map(str, t.shape)) for t in sd.values()] == list(g["shapes_%s_%d" % (v, s)])
+        assert [k for k in sd if xo.is_parameter(k)] == list(g["params_%s_%d" % (v, s)])
+    assert len(xo.state_template("M")) == 820
+
+
+@pytest.mark.parametrize("case", ["train_M_2x4x32_s1", "train_M_8x4x64_s2", "train_M_16x2x47_s4",
+                                  "train_M_2x4x111_s1", "train_M_2x4x158_s2", "train_M_2x8x112_s1"])
+def test_train_step_matches_reference(golden_dir, case):
+    g = _load(golden_dir, case)
+    B, T, H, S = [int(v) for v in g["shape"]]
+    torch.set_num_threads(8)
+    sd = synthetic.procedural_state_dict(xo.state_template("M", 400, S), int(g["seed"][0]))
+    x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1]))
+    y = synthetic.synthetic_labels(B, seed=int(g["seed"][1]))
+    logits, loss, grads, new_stats = xo.train_step_grads(x, y, sd, "M", S)
+    parity.check_forward(logits[:, :, 0].numpy(), loss.item(), g, rtol=RTOL)
+    parity.check_grads({k: v.numpy() for k, v in grads.items()}, g, synthetic.gradient_sketch)
+    parity.check_bn_stats({k: v.numpy() for k, v in new_stats.items() if v.ndim}, g, rtol=RTOL)
+    # aggregation + eval forward on the same clip
+    sd2 = dict(sd)
+    sd2.update(new_stats)
+    agg = xo.aggregate_sub_bn(sd2, S)
+    assert len(agg) // 2 == int(g["n_agg"])
+    for k in g.files:
+        if k.startswith("agg_rm/"):
+            assert _rel(agg[k[7:] + ".bn.running_mean"].numpy(), g[k]) < RTOL, k
+        if k.startswith("agg_rv/"):
+            assert _rel(agg[k[7:] + ".bn.running_var"].numpy(), g[k]) < RTOL, k
+    sd2.update(agg)
+    with torch.no_grad():
+        ev = xo.forward(x, sd2, "M", S, training=False)
+    assert _rel(ev[:, :, 0].numpy(), g["eval_logits"]) < RTOL
+
+
+def test_eval_forward_S_config1(golden_dir):
+    g = _load(golden_dir, "eval_S_2x13x160")
+    sd = synthetic.procedural_state_dict(xo.state_template("S", 400, 1), 0)
+    x = synthetic.synthetic_clips(2, 13, 160, 160)
+    with torch.no_grad():
+        logits = xo.forward(x, sd, "S", 1, training=False)
+    assert logits.shape == (2, 400, 1)
+    assert _rel(logits[:, :, 0].numpy(), g["logits"]) < RTOL
+
+
+def test_sampler_sequences(golden_dir):
+    g = _load(golden_dir, "sampler")
+    sch = list(g["schedule_full"])
+    assert sch == [0, 82464, 134004, 175236, 206160]
+    got = mo.ScheduleState(128, sch, 0, [8, 4, 2, 1]).batches(12)
+    assert [b for b, _ in got] == list(g["full_first_len"])
+    assert [l for _, l in got] == list(g["full_first_long"])
+    got = mo.ScheduleState(128, sch, 204000, [8, 4, 2, 1]).batches(12)
+    assert [b for b, _ in got] == list(g["full_resume_len"])
+    assert [l for _, l in got] == list(g["full_resume_long"])
+    small = list(g["schedule_small"])
+    got = mo.ScheduleState(8, small, 0, [8, 4, 2, 1]).batches(400)
+    assert [b for b, _ in got] == list(g["small_len"])
+    assert [l for _, l in got] == list(g["small_long"])
+    got = mo.ScheduleState(8, small, 200, [8, 4, 2, 1]).batches(150)
+    assert [b for b, _ in got] == list(g["small_resume_len"])
+    assert [l for _, l in got] == list(g["small_resume_long"])
+    got = mo.ScheduleState(1, sch, 0, [8, 4, 2, 1]).batches(206100)
+    longs = np.array([l for _, l in got])
+    chg = np.nonzero(np.diff(longs))[0] + 1
+    assert list(chg) == list(g["full_transitions_at"])
+    assert list(longs[chg]) == list(g["full_transitions_to"])
+    with pytest.raises(IndexError):
+        mo.ScheduleState(1, sch, 206100, [8, 4, 2, 1]).batches(200)
+
+
+def test_shape_table_matches_survey():
+    # canonical X3D-M, frames=80, gamma_tau=5, crop 224
+    exp = {0: [(4, 111), (4, 158)], 1: [(8, 111), (8, 158)],
+           2: [(8, 112), (8, 158), (8, 224)], 3: [(16, 112), (16, 158), (16, 224)],
+           -1: [(16, 112), (16, 158), (16, 224)]}
+    for li, shapes in exp.items():
+        got = [mo.step_shape(li, t, 80, 5) for t in range(len(shapes))]
+        assert got == shapes
+    assert mo.lr_milestones(206160) == [82464, 134004, 190698, 206160]
