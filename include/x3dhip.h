@@ -1,0 +1,215 @@
+/*
+ * x3dhip.h -- C ABI of libx3dhip.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * X3D training hot path.
+ *
+ * The reference (KiyoshiKAWASAKI/X3D-Multigrid) has no FFI of its own: every FLOP of
+ * x3d.py runs inside PyTorch (ATen/cuDNN/oneDNN).  The boundary replaced here is therefore
+ * the set of ATen ops x3d.py calls, re-cut so that elementwise work rides in the prologue
+ * or epilogue of the convolution that produces/consumes it.  Each entry point cites the
+ * reference call site(s) it replaces (file:line in /root/reference).
+ *
+ * Conventions
+ *   - all tensors fp32, NCTHW contiguous (x3d.py:316), P = T*H*W
+ *   - plain pointers and sizes; the caller (torch) owns every buffer; no hidden allocation,
+ *     no hidden synchronisation; every kernel is enqueued on the hipStream_t passed as
+ *     `stream` (void* in this header so that C callers need no HIP headers)
+ *   - return 0 on success, negative X3D_E* on failure; x3d_last_error() gives the message
+ *     (thread-local); no C++ exception crosses the boundary; thread-safe, re-entrant
+ *   - "coef" arrays are per-(sample, channel): the split-BN's interleaved sample->split map
+ *     (x3d.py:50-52) is resolved when they are built, so conv kernels never see splits
+ *   - "partial" arrays hold per-workgroup partial reductions that a finalize kernel sums in
+ *     fixed order in fp64 (bitwise reproducible; no float atomics anywhere)
+ */
+#ifndef X3DHIP_H
+#define X3DHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X3D_ABI_VERSION 1
+
+#define X3D_OK 0
+#define X3D_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define X3D_ELAUNCH (-2)  /* hipLaunch error */
+
+/* activation selectors for fused prologues / epilogues */
+#define X3D_ACT_NONE 0
+#define X3D_ACT_RELU 1   /* nn.ReLU           x3d.py:119,148,169,210 */
+#define X3D_ACT_SWISH 2  /* SwishEfficient    x3d.py:71-84 */
+
+int x3d_abi_version(void);
+const char* x3d_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Pointwise 1x1x1 convolution  (conv1x1x1 x3d.py:98-103; Bottleneck.conv1/conv3 :112,116;
+ * downsample[0] :272; conv5 :231) as an fp32 MFMA GEMM  Y[co,p] = sum_ci W[co,ci] * in[ci,p].
+ * ---------------------------------------------------------------------------------- */
+
+/* number of position tiles per sample the pw kernels use for `partial` (P = output T*H*W) */
+int x3d_pw_tiles(int P);
+
+/* Forward.  in[ci,p] = act(pre[n,ci,0] * x + pre[n,ci,1]) when pre != NULL (fuses the
+ * producer's BN-apply + ReLU, or BN-apply * SE-scale + Swish: x3d.py:147-148,151-160), else x.
+ * strideHW in {1,2}: 2 = the downsample conv's (1,2,2) stride (x3d.py:101), x is [N,Cin,T,H,W]
+ * and y is [N,Cout,T,Ho,Wo].  partial (may be NULL) receives per-(n,co,tile) {sum y, sum y^2}
+ * as float[N][Cout][x3d_pw_tiles(Po)][2] for the BN that follows (x3d.py:51). */
+int x3d_pw_fwd(const float* x, const float* w, float* y,
+               int N, int Cin, int Cout, int T, int H, int W, int strideHW,
+               const float* pre, int pre_act,
+               float* partial, void* stream);
+
+/* Backward-data (autograd of the conv above, fused with the BN backward that precedes it in
+ * the backward pass and with the activation backward that follows it):
+ *   dY[co,p]  = cb[n,co,0]*g[co,p] + cb[n,co,1]*a[co,p] + cb[n,co,2]    (BN backward, see
+ *               x3d_bn_bwd_finalize; g = upstream gradient, a = raw conv output saved in fwd)
+ *   dIn[ci,p] = sum_co W[co,ci] * dY[co,p]  (+ addend[ci,p'] when addend != NULL; with
+ *               addend_stride 2 the addend is [N,Cin,T,Ho,Wo] and only lands on even (h,w))
+ *   out       = dIn                                     when pre == NULL
+ *             = dIn * act'(pre[n,ci,0]*x + pre[n,ci,1]) when pre != NULL (x = raw producer
+ *               output; SwishEfficient.backward x3d.py:80-84 / ReLU backward)
+ * partial (NULL unless pre != NULL) gets per-(n,ci,tile) {sum out, sum out*x}.
+ * Geometry: g,a are [N,Cout,T,H,W]; out,x are [N,Cin,T,H,W]. */
+int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float* w,
+                    float* out, int N, int Cin, int Cout, int T, int H, int W,
+                    const float* x, const float* pre, int pre_act,
+                    const float* addend, int addend_stride,
+                    float* partial, void* stream);
+
+/* Backward-weight: dW[co,ci] = sum_{n,p} dY[co,p] * in[ci,p] with dY and in formed as above
+ * (strideHW 2: in is sampled at even (h,w) of x[N,Cin,T,H,W]; g,a are at output resolution).
+ * wpartial is float[x3d_pw_wgrad_groups(...)][Cout][Cin]; x3d_reduce_partials sums it. */
+int x3d_pw_wgrad_groups(int N, int P);
+int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb,
+                      const float* x, const float* pre, int pre_act,
+                      float* wpartial, int N, int Cin, int Cout, int T, int H, int W,
+                      int strideHW, void* stream);
+
+/* out[i] = sum_g partial[g][i], g < groups, i < n  (fixed order, fp64 accumulate) */
+int x3d_reduce_partials(const float* partial, float* out, int groups, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Channelwise 3x3x3 convolution (conv3x3x3 x3d.py:87-95, Bottleneck.conv2 :114,150):
+ * groups=C, pad 1, stride (1,s,s), no bias.  HBM-bound; LDS-staged T-marching stencil.
+ * ---------------------------------------------------------------------------------- */
+int x3d_dw_tiles(int H_out, int W_out);  /* spatial tiles per (n,c) used for `partial` */
+
+/* y = dw333(relu(pre*x+pre) zero-padded).  partial: float[N][C][tiles][2] {sum y, sum y^2}. */
+int x3d_dw333_fwd(const float* x, const float* w, float* y,
+                  int N, int C, int T, int H, int W, int strideHW,
+                  const float* pre, int pre_act, float* partial, void* stream);
+
+/* Fused backward (data + weight) of the conv above:
+ *   dY = cb0*g + cb1*a + cb2 (g,a at output resolution [N,C,T,Ho,Wo])
+ *   hin = act(pre*x+pre)  (x raw [N,C,T,H,W])
+ *   out = dw333^T(dY) * act'(pre*x+pre)           -> [N,C,T,H,W]
+ *   dW[c,kt,kh,kw] partials: float[N][C][x3d_dw_bwd_tiles(H,W,s)][27]
+ *   partial: float[N][C][x3d_dw_bwd_tiles(H,W,s)][2] {sum out, sum out*x}  */
+int x3d_dw_bwd_tiles(int H, int W, int strideHW);
+int x3d_dw333_bwd(const float* g, const float* a, const float* cb, const float* w,
+                  const float* x, const float* pre, int pre_act,
+                  float* out, float* wpartial, float* partial,
+                  int N, int C, int T, int H, int W, int strideHW, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Stem (x3d.py:196-208,317-318): dense 1x3x3 s(1,2,2) 3->C, then depthwise temporal 5x1x1.
+ * ---------------------------------------------------------------------------------- */
+int x3d_stem133_fwd(const float* x, const float* w, float* y,
+                    int N, int Cin, int Cout, int T, int H, int W, void* stream);
+/* dW[co,ci,kh,kw] partials float[x3d_stem_wgrad_groups(N,T)][Cout][Cin*9] from dy[N,Cout,T,Ho,Wo] */
+int x3d_stem_wgrad_groups(int N, int T);
+int x3d_stem133_bwd_weight(const float* x, const float* dy, float* wpartial,
+                           int N, int Cin, int Cout, int T, int H, int W, void* stream);
+/* y = dw5t(x) (pad (2,0,0)); partial float[N][C][x3d_dw5t_tiles(HW)][2] {sum y, sum y^2} */
+int x3d_dw5t_tiles(int HW);
+int x3d_dw5t_fwd(const float* x, const float* w, float* y, int N, int C, int T, int HW,
+                 float* partial, void* stream);
+/* dY = cb0*g+cb1*a+cb2; dx = dw5t^T(dY); dW partials float[N][C][tiles][5] (x = conv1_s output) */
+int x3d_dw5t_bwd(const float* g, const float* a, const float* cb, const float* w, const float* x,
+                 float* dx, float* wpartial, int N, int C, int T, int HW, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Split BatchNorm3d (SubBatchNorm3d x3d.py:9-58) finalisation kernels (tiny).
+ * ---------------------------------------------------------------------------------- */
+
+/* bytes of device scratch the finalize entry points below need (fp64 tile sums etc.) */
+size_t x3d_finalize_scratch_bytes(int N, int C, int Wd);
+
+/* Training forward: reduce partial[N][C][tiles][2] over the samples of each split
+ * (sample n belongs to split n % S, x3d.py:50), produce
+ *   coef[n][c] = {gamma*invstd, beta - mean*gamma*invstd}  (BN + affine, x3d.py:51-57)
+ *   save[0][j][c] = mean, save[1][j][c] = invstd           (float[2][S][C])
+ *   nsum[n][c]   = sum_p raw[n,c,p]                        (for SE pooling / its backward)
+ *   running_mean/var[j*C+c] updated with momentum 0.1, unbiased variance (nn.BatchNorm3d).
+ * count = elements per (n,c) = T*H*W of the normalised tensor. */
+int x3d_bn_fwd_finalize(const float* partial, int N, int C, int tiles, int S, int count,
+                        const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps,
+                        float* coef, float* save, float* nsum, void* scratch, void* stream);
+
+/* Eval forward: coef from the aggregated running stats (x3d.py:54, bn branch). */
+int x3d_bn_eval_coef(const float* running_mean, const float* running_var,
+                     const float* gamma, const float* beta, float eps,
+                     int N, int C, float* coef, void* stream);
+
+/* Squeeze-excitation forward on pooled statistics (x3d.py:153-159): for every sample
+ *   pool[c] = coef[n][c][0]*nsum[n][c]/count + coef[n][c][1]   (global average of BN output)
+ *   z = relu(W1 pool + b1); se = sigmoid(W2 z + b2)
+ *   coef_out[n][c] = coef[n][c] * se[c]      (so the consumer's prologue computes swish(bn*se))
+ * save_se: float[N][C] (se), save_z: float[N][Wd] (post-relu hidden). */
+int x3d_se_fwd(const float* coef, const float* nsum, int N, int C, int Wd, int count,
+               const float* w1, const float* b1, const float* w2, const float* b2,
+               float* coef_out, float* save_se, float* save_z, float* save_pool, void* stream);
+
+/* BN backward finalisation.  partial[N][C][tiles][2] = {sum g, sum g*raw} per (n,c,tile) where
+ * g is the gradient w.r.t. the BN+affine output.  Produces
+ *   cb[n][c] = {A, B, Cc} with d(raw) = A*g + B*raw + Cc   (nn.BatchNorm3d training backward)
+ *   dgamma[c] (+)= sum g*xhat, dbeta[c] (+)= sum g      (accumulate != 0 adds to existing) */
+int x3d_bn_bwd_finalize(const float* partial, int N, int C, int tiles, int S, int count,
+                        const float* gamma, const float* save,
+                        float* cb, float* dgamma, float* dbeta, int accumulate,
+                        void* scratch, void* stream);
+
+/* BN2 + SE backward finalisation (Bottleneck with SE).  partial = {sum ds, sum ds*raw} where
+ * ds is the gradient w.r.t. s = bn2(raw)*se (already through swish').  Computes the SE
+ * gradients (dW1,db1,dW2,db2), and cb such that d(raw) = A*ds + B*raw + Cc. */
+int x3d_se_bn_bwd_finalize(const float* partial, int N, int C, int tiles, int S, int count,
+                           const float* gamma, const float* beta, const float* save,
+                           const float* nsum,
+                           int Wd, const float* w1, const float* w2,
+                           const float* save_se, const float* save_z, const float* save_pool,
+                           float* cb, float* dgamma, float* dbeta,
+                           float* dw1, float* db1, float* dw2, float* db2,
+                           void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Residual epilogue (x3d.py:165-169): out = relu(c3*a3 + res) with res = x (identity) or
+ * cd*ad (downsample branch BN).  Backward: g = dout*(out>0), partial {sum g, sum g*a3}
+ * (and {sum g, sum g*ad} in partial_d when ad != NULL).
+ * ---------------------------------------------------------------------------------- */
+int x3d_ew_tiles(int P);
+int x3d_bn_add_relu_fwd(const float* a3, const float* c3, const float* res, const float* cd,
+                        float* out, int N, int C, int P, void* stream);
+int x3d_bn_add_relu_bwd(const float* dout, const float* out, const float* a3, const float* ad,
+                        float* g, float* partial, float* partial_d,
+                        int N, int C, int P, void* stream);
+
+/* Head pooling (x3d.py:328-331): pooled[n][c] = mean_p relu(c5*a5).  Backward:
+ * g = dpooled/P * (c5*a5 > 0), partial {sum g, sum g*a5}. */
+int x3d_bn_relu_pool_fwd(const float* a5, const float* c5, float* pooled,
+                         int N, int C, int P, void* stream);
+int x3d_bn_relu_pool_bwd(const float* a5, const float* c5, const float* dpooled,
+                         float* g, float* partial, int N, int C, int P, void* stream);
+
+/* Fused SGD (torch.optim.SGD, train_x3d_kinetics_multigrid.py:183): g += wd*w;
+ * m = first ? g : mu*m + g; w -= lr*m.  grad_scale multiplies g first (1/world_size). */
+int x3d_sgd_fused(float* w, const float* g, float* m, size_t n, float lr, float momentum,
+                  float weight_decay, float grad_scale, int first, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X3DHIP_H */

@@ -1,0 +1,531 @@
+// Split-BatchNorm finalisation, squeeze-excitation on pooled statistics, residual epilogue,
+// head pooling and fused SGD.
+//
+// Reference call sites replaced: SubBatchNorm3d.forward (x3d.py:47-58) and its autograd
+// backward; SE branch of Bottleneck.forward (x3d.py:153-159); `out += residual; relu`
+// (x3d.py:165-169); bn5/relu/avgpool (x3d.py:327-331); torch.optim.SGD step
+// (train_x3d_kinetics_multigrid.py:183,277).
+//
+// None of these touch a full activation tensor except the residual epilogue and the head
+// pool: BN statistics arrive as per-(sample, channel, tile) partial sums written by the conv
+// epilogues; the kernels here reduce them in fp64 in a fixed order and emit the
+// per-(sample, channel) coefficients the next conv applies on load.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// tile reduction: partial[N*C][tiles][NV] (float) -> dsum[N*C][NV] (double); one wave per row
+// ------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void reduce_tiles_kernel(const float* __restrict__ partial,
+                                                           double* __restrict__ dsum, int rows, int tiles) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    double s[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s[v] = 0.0;
+    const float* p = partial + (size_t)row * tiles * NV;
+    for (int t = lane; t < tiles; t += 64) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) s[v] += (double)p[(size_t)t * NV + v];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double x = s[v];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if (lane == 0) dsum[(size_t)row * NV + v] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BN forward finalize (thread per channel)
+// ------------------------------------------------------------------------------------
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ dsum, int N, int C, int S, int count,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                       float eps, float* __restrict__ coef, float* __restrict__ save,
+                                       float* __restrict__ nsum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double cnt = (double)count * (double)(N / S);
+    const float g = gamma[c], b = beta[c];
+    for (int j = 0; j < S; ++j) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int n = j; n < N; n += S) {
+            s1 += dsum[((size_t)n * C + c) * 2];
+            s2 += dsum[((size_t)n * C + c) * 2 + 1];
+        }
+        const double mean = s1 / cnt;
+        double var = s2 / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        save[(size_t)j * C + c] = (float)mean;
+        save[(size_t)(S + j) * C + c] = (float)invstd;
+        if (rmean != nullptr) {
+            const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            rmean[(size_t)j * C + c] = (float)((1.0 - momentum) * rmean[(size_t)j * C + c] + momentum * mean);
+            rvar[(size_t)j * C + c] = (float)((1.0 - momentum) * rvar[(size_t)j * C + c] + momentum * unb);
+        }
+        const float sc = (float)((double)g * invstd);
+        const float sh = (float)((double)b - mean * (double)g * invstd);
+        for (int n = j; n < N; n += S) {
+            coef[((size_t)n * C + c) * 2] = sc;
+            coef[((size_t)n * C + c) * 2 + 1] = sh;
+            if (nsum != nullptr) nsum[(size_t)n * C + c] = (float)dsum[((size_t)n * C + c) * 2];
+        }
+    }
+}
+
+__global__ void bn_eval_coef_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                    int N, int C, float* __restrict__ coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int c = i % C;
+    const double invstd = 1.0 / sqrt((double)rvar[c] + (double)eps);
+    coef[(size_t)i * 2] = (float)((double)gamma[c] * invstd);
+    coef[(size_t)i * 2 + 1] = (float)((double)beta[c] - (double)rmean[c] * (double)gamma[c] * invstd);
+}
+
+// ------------------------------------------------------------------------------------
+// SE forward: one workgroup per sample
+// ------------------------------------------------------------------------------------
+constexpr int SE_MAXC = 1024, SE_MAXW = 64;
+
+__global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ coef, const float* __restrict__ nsum,
+                                                     int C, int Wd, int count, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, float* __restrict__ coef_out,
+                                                     float* __restrict__ save_se, float* __restrict__ save_z,
+                                                     float* __restrict__ save_pool) {
+    __shared__ float pool[SE_MAXC];
+    __shared__ float z[SE_MAXW];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        const float sc = coef[((size_t)n * C + c) * 2], sh = coef[((size_t)n * C + c) * 2 + 1];
+        const float p = fmaf(sc, nsum[(size_t)n * C + c] / (float)count, sh);
+        pool[c] = p;
+        save_pool[(size_t)n * C + c] = p;
+    }
+    __syncthreads();
+    for (int w = wave; w < Wd; w += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w1[(size_t)w * C + c], pool[c], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            s += b1[w];
+            s = s > 0.f ? s : 0.f;
+            z[w] = s;
+            save_z[(size_t)n * Wd + w] = s;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = b2[c];
+        for (int w = 0; w < Wd; ++w) s = fmaf(w2[(size_t)c * Wd + w], z[w], s);
+        const float se = sigmoidf_(s);
+        save_se[(size_t)n * C + c] = se;
+        coef_out[((size_t)n * C + c) * 2] = coef[((size_t)n * C + c) * 2] * se;
+        coef_out[((size_t)n * C + c) * 2 + 1] = coef[((size_t)n * C + c) * 2 + 1] * se;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BN backward finalize (thread per channel).  dsum[n][c] = {sum g, sum g*raw}.
+// extra (optional, SE variant): per-(n,c) arrays modifying the upstream gradient
+//   g_full = se[n,c]*g + dpool[n,c]/count
+// ------------------------------------------------------------------------------------
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ dsum, int N, int C, int S, int count,
+                                       const float* __restrict__ gamma, const float* __restrict__ save,
+                                       const float* __restrict__ se, const float* __restrict__ dpool,
+                                       const float* __restrict__ nsum, float* __restrict__ cb,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double M = (double)count * (double)(N / S);
+    const double g = gamma[c];
+    double dg = 0.0, db = 0.0;
+    for (int j = 0; j < S; ++j) {
+        const double mean = save[(size_t)j * C + c], invstd = save[(size_t)(S + j) * C + c];
+        double sg = 0.0, sgx = 0.0;
+        for (int n = j; n < N; n += S) {
+            const double d0 = dsum[((size_t)n * C + c) * 2], d1 = dsum[((size_t)n * C + c) * 2 + 1];
+            if (se != nullptr) {
+                const double sv = se[(size_t)n * C + c], dp = dpool[(size_t)n * C + c];
+                sg += sv * d0 + dp;
+                sgx += sv * (d1 - mean * d0) * invstd +
+                       (dp / (double)count) * ((double)nsum[(size_t)n * C + c] - (double)count * mean) * invstd;
+            } else {
+                sg += d0;
+                sgx += (d1 - mean * d0) * invstd;
+            }
+        }
+        dg += sgx;
+        db += sg;
+        const double k = g * invstd;
+        const double Bc = -k * invstd * sgx / M;
+        const double Cbase = -k * sg / M + k * invstd * mean * sgx / M;
+        for (int n = j; n < N; n += S) {
+            double Ac = k, Cc = Cbase;
+            if (se != nullptr) {
+                Ac = k * (double)se[(size_t)n * C + c];
+                Cc += k * (double)dpool[(size_t)n * C + c] / (double)count;
+            }
+            cb[((size_t)n * C + c) * 3] = (float)Ac;
+            cb[((size_t)n * C + c) * 3 + 1] = (float)Bc;
+            cb[((size_t)n * C + c) * 3 + 2] = (float)Cc;
+        }
+    }
+    if (accumulate) {
+        dgamma[c] += (float)dg;
+        dbeta[c] += (float)db;
+    } else {
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
+    }
+}
+
+// SE backward, one workgroup per sample.  Writes dpool[n][c], dz2[n][c], dz1[n][w].
+__global__ __launch_bounds__(256) void se_bwd_sample_kernel(
+    const double* __restrict__ dsum, int C, int S, int Wd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ save, const float* __restrict__ w1,
+    const float* __restrict__ w2, const float* __restrict__ save_se, const float* __restrict__ save_z,
+    float* __restrict__ dpool, float* __restrict__ dz2o, float* __restrict__ dz1o) {
+    __shared__ float dz2[SE_MAXC];
+    __shared__ float dz1[SE_MAXW];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = n % S;
+    for (int c = tid; c < C; c += 256) {
+        const double mean = save[(size_t)j * C + c], invstd = save[(size_t)(S + j) * C + c];
+        const double k = (double)gamma[c] * invstd, h = (double)beta[c] - mean * k;
+        const double d0 = dsum[((size_t)n * C + c) * 2], d1 = dsum[((size_t)n * C + c) * 2 + 1];
+        const float dse = (float)(k * d1 + h * d0);
+        const float sv = save_se[(size_t)n * C + c];
+        const float v = dse * sv * (1.f - sv);
+        dz2[c] = v;
+        dz2o[(size_t)n * C + c] = v;
+    }
+    __syncthreads();
+    for (int w = wave; w < Wd; w += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w2[(size_t)c * Wd + w], dz2[c], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float v = save_z[(size_t)n * Wd + w] > 0.f ? s : 0.f;
+            dz1[w] = v;
+            dz1o[(size_t)n * Wd + w] = v;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int w = 0; w < Wd; ++w) s = fmaf(w1[(size_t)w * C + c], dz1[w], s);
+        dpool[(size_t)n * C + c] = s;
+    }
+}
+
+// SE weight gradients: thread per (c, w) pair; sums over samples in order.
+__global__ void se_wgrad_kernel(int N, int C, int Wd, const float* __restrict__ dz2, const float* __restrict__ dz1,
+                                const float* __restrict__ save_z, const float* __restrict__ save_pool,
+                                float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                float* __restrict__ db2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * Wd) return;
+    const int c = i / Wd, w = i - c * Wd;
+    double a2 = 0.0, a1 = 0.0, bb2 = 0.0, bb1 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const double d2 = dz2[(size_t)n * C + c], d1 = dz1[(size_t)n * Wd + w];
+        a2 += d2 * (double)save_z[(size_t)n * Wd + w];
+        a1 += d1 * (double)save_pool[(size_t)n * C + c];
+        bb2 += d2;
+        bb1 += d1;
+    }
+    dw2[(size_t)c * Wd + w] = (float)a2;
+    dw1[(size_t)w * C + c] = (float)a1;
+    if (w == 0) db2[c] = (float)bb2;
+    if (c == 0) db1[w] = (float)bb1;
+}
+
+// ------------------------------------------------------------------------------------
+// Residual epilogue, head pooling (elementwise, HBM-bound; float4 when P % 4 == 0)
+// ------------------------------------------------------------------------------------
+constexpr int EW_TILE = 2048;   // elements per workgroup tile (256 threads x 2 float4)
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __restrict__ a3, const float* __restrict__ c3,
+                                                              const float* __restrict__ res, const float* __restrict__ cd,
+                                                              float* __restrict__ out, int P) {
+    const int row = blockIdx.y;
+    const float sc = c3[(size_t)row * 2], sh = c3[(size_t)row * 2 + 1];
+    float rc = 1.f, rh = 0.f;
+    if (cd != nullptr) { rc = cd[(size_t)row * 2]; rh = cd[(size_t)row * 2 + 1]; }
+    const size_t base = (size_t)row * P;
+    const int p0 = blockIdx.x * EW_TILE;
+    if (VEC) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + (u * 256 + threadIdx.x) * 4;
+            if (p < P) {
+                const float4 a = *reinterpret_cast<const float4*>(a3 + base + p);
+                const float4 r = *reinterpret_cast<const float4*>(res + base + p);
+                float4 o;
+                o.x = fmaxf(fmaf(sc, a.x, sh) + fmaf(rc, r.x, rh), 0.f);
+                o.y = fmaxf(fmaf(sc, a.y, sh) + fmaf(rc, r.y, rh), 0.f);
+                o.z = fmaxf(fmaf(sc, a.z, sh) + fmaf(rc, r.z, rh), 0.f);
+                o.w = fmaxf(fmaf(sc, a.w, sh) + fmaf(rc, r.w, rh), 0.f);
+                *reinterpret_cast<float4*>(out + base + p) = o;
+            }
+        }
+    } else {
+        for (int p = p0 + threadIdx.x; p < min(P, p0 + EW_TILE); p += 256)
+            out[base + p] = fmaxf(fmaf(sc, a3[base + p], sh) + fmaf(rc, res[base + p], rh), 0.f);
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                              const float* __restrict__ a3, const float* __restrict__ ad,
+                                                              float* __restrict__ g, float* __restrict__ partial,
+                                                              float* __restrict__ partial_d, int P, int tiles) {
+    __shared__ float red[4 * 3];
+    const int row = blockIdx.y;
+    const size_t base = (size_t)row * P;
+    const int p0 = blockIdx.x * EW_TILE;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (VEC) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + (u * 256 + threadIdx.x) * 4;
+            if (p < P) {
+                const float4 d = *reinterpret_cast<const float4*>(dout + base + p);
+                const float4 o = *reinterpret_cast<const float4*>(out + base + p);
+                const float4 a = *reinterpret_cast<const float4*>(a3 + base + p);
+                float4 gg;
+                gg.x = o.x > 0.f ? d.x : 0.f;
+                gg.y = o.y > 0.f ? d.y : 0.f;
+                gg.z = o.z > 0.f ? d.z : 0.f;
+                gg.w = o.w > 0.f ? d.w : 0.f;
+                *reinterpret_cast<float4*>(g + base + p) = gg;
+                v[0] += (gg.x + gg.y) + (gg.z + gg.w);
+                v[1] += fmaf(gg.x, a.x, fmaf(gg.y, a.y, fmaf(gg.z, a.z, gg.w * a.w)));
+                if (ad != nullptr) {
+                    const float4 b = *reinterpret_cast<const float4*>(ad + base + p);
+                    v[2] += fmaf(gg.x, b.x, fmaf(gg.y, b.y, fmaf(gg.z, b.z, gg.w * b.w)));
+                }
+            }
+        }
+    } else {
+        for (int p = p0 + threadIdx.x; p < min(P, p0 + EW_TILE); p += 256) {
+            const float gg = out[base + p] > 0.f ? dout[base + p] : 0.f;
+            g[base + p] = gg;
+            v[0] += gg;
+            v[1] = fmaf(gg, a3[base + p], v[1]);
+            if (ad != nullptr) v[2] = fmaf(gg, ad[base + p], v[2]);
+        }
+    }
+    float o3[3];
+    block_sum_256<3>(v, red, o3);
+    if (threadIdx.x == 0) {
+        partial[((size_t)row * tiles + blockIdx.x) * 2] = o3[0];
+        partial[((size_t)row * tiles + blockIdx.x) * 2 + 1] = o3[1];
+        if (partial_d != nullptr) {
+            partial_d[((size_t)row * tiles + blockIdx.x) * 2] = o3[0];
+            partial_d[((size_t)row * tiles + blockIdx.x) * 2 + 1] = o3[2];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ a5, const float* __restrict__ c5,
+                                                               float* __restrict__ pooled, int P) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float sc = c5[(size_t)row * 2], sh = c5[(size_t)row * 2 + 1];
+    const float* p = a5 + (size_t)row * P;
+    float v[1] = {0.f};
+    for (int i = threadIdx.x; i < P; i += 256) v[0] += fmaxf(fmaf(sc, p[i], sh), 0.f);
+    float o[1];
+    block_sum_256<1>(v, red, o);
+    if (threadIdx.x == 0) pooled[row] = o[0] / (float)P;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __restrict__ a5, const float* __restrict__ c5,
+                                                               const float* __restrict__ dpooled, float* __restrict__ g,
+                                                               float* __restrict__ partial, int P, int tiles) {
+    __shared__ float red[4 * 2];
+    const int row = blockIdx.y;
+    const float sc = c5[(size_t)row * 2], sh = c5[(size_t)row * 2 + 1];
+    const float d = dpooled[row] / (float)P;
+    const size_t base = (size_t)row * P;
+    const int p0 = blockIdx.x * EW_TILE;
+    float v[2] = {0.f, 0.f};
+    for (int p = p0 + threadIdx.x; p < min(P, p0 + EW_TILE); p += 256) {
+        const float a = a5[base + p];
+        const float gg = fmaf(sc, a, sh) > 0.f ? d : 0.f;
+        g[base + p] = gg;
+        v[0] += gg;
+        v[1] = fmaf(gg, a, v[1]);
+    }
+    float o[2];
+    block_sum_256<2>(v, red, o);
+    if (threadIdx.x == 0) {
+        partial[((size_t)row * tiles + blockIdx.x) * 2] = o[0];
+        partial[((size_t)row * tiles + blockIdx.x) * 2 + 1] = o[1];
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                  size_t n, float lr, float mu, float wd, float gs, int first) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float wi = w[i];
+    const float gi = fmaf(wd, wi, g[i] * gs);
+    const float mi = first ? gi : fmaf(mu, m[i], gi);
+    m[i] = mi;
+    w[i] = wi - lr * mi;
+}
+
+}  // namespace
+
+extern "C" int x3d_ew_tiles(int P) { return cdiv(P, EW_TILE); }
+
+extern "C" size_t x3d_finalize_scratch_bytes(int N, int C, int Wd) {
+    return (size_t)N * C * 2 * sizeof(double) + ((size_t)N * C * 2 + (size_t)N * Wd) * sizeof(float) + 64;
+}
+
+extern "C" int x3d_bn_fwd_finalize(const float* partial, int N, int C, int tiles, int S, int count,
+                                   const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* coef, float* save,
+                                   float* nsum, void* scratch, void* stream) {
+    X3D_CHECK_ARG(partial && gamma && beta && coef && save && scratch);
+    X3D_CHECK_ARG(N > 0 && C > 0 && tiles > 0 && S > 0 && count > 0);
+    if (N % S != 0) {
+        x3d_set_error("split BN needs batch %% num_splits == 0 (got N=%d, splits=%d; x3d.py:50)", N, S);
+        return X3D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    double* dsum = (double*)scratch;
+    hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dsum, N, C, S, count, gamma,
+                       beta, running_mean, running_var, momentum, eps, coef, save, nsum);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_bn_eval_coef(const float* running_mean, const float* running_var, const float* gamma,
+                                const float* beta, float eps, int N, int C, float* coef, void* stream) {
+    X3D_CHECK_ARG(running_mean && running_var && gamma && beta && coef && N > 0 && C > 0);
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       running_mean, running_var, gamma, beta, eps, N, C, coef);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_se_fwd(const float* coef, const float* nsum, int N, int C, int Wd, int count, const float* w1,
+                          const float* b1, const float* w2, const float* b2, float* coef_out, float* save_se,
+                          float* save_z, float* save_pool, void* stream) {
+    X3D_CHECK_ARG(coef && nsum && w1 && b1 && w2 && b2 && coef_out && save_se && save_z && save_pool);
+    X3D_CHECK_ARG(N > 0 && C > 0 && C <= SE_MAXC && Wd > 0 && Wd <= SE_MAXW && count > 0);
+    hipLaunchKernelGGL(se_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, coef, nsum, C, Wd, count, w1, b1,
+                       w2, b2, coef_out, save_se, save_z, save_pool);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_bn_bwd_finalize(const float* partial, int N, int C, int tiles, int S, int count,
+                                   const float* gamma, const float* save, float* cb, float* dgamma, float* dbeta,
+                                   int accumulate, void* scratch, void* stream) {
+    X3D_CHECK_ARG(partial && gamma && save && cb && dgamma && dbeta && scratch);
+    X3D_CHECK_ARG(N > 0 && C > 0 && tiles > 0 && S > 0 && count > 0 && N % S == 0);
+    hipStream_t s = (hipStream_t)stream;
+    double* dsum = (double*)scratch;
+    hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dsum, N, C, S, count, gamma, save,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cb, dgamma, dbeta,
+                       accumulate);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_se_bn_bwd_finalize(const float* partial, int N, int C, int tiles, int S, int count,
+                                      const float* gamma, const float* beta, const float* save, const float* nsum,
+                                      int Wd, const float* w1, const float* w2, const float* save_se,
+                                      const float* save_z, const float* save_pool, float* cb, float* dgamma,
+                                      float* dbeta, float* dw1, float* db1, float* dw2, float* db2, void* scratch,
+                                      void* stream) {
+    X3D_CHECK_ARG(partial && gamma && beta && save && nsum && w1 && w2 && save_se && save_z && save_pool);
+    X3D_CHECK_ARG(cb && dgamma && dbeta && dw1 && db1 && dw2 && db2 && scratch);
+    X3D_CHECK_ARG(N > 0 && C > 0 && C <= SE_MAXC && Wd > 0 && Wd <= SE_MAXW && tiles > 0 && S > 0 && N % S == 0);
+    hipStream_t s = (hipStream_t)stream;
+    double* dsum = (double*)scratch;
+    float* dpool = (float*)(dsum + (size_t)N * C * 2);
+    float* dz2 = dpool + (size_t)N * C;
+    float* dz1 = dz2 + (size_t)N * C;
+    hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
+    hipLaunchKernelGGL(se_bwd_sample_kernel, dim3(N), dim3(256), 0, s, dsum, C, S, Wd, gamma, beta, save, w1, w2,
+                       save_se, save_z, dpool, dz2, dz1);
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3(cdiv(C * Wd, 256)), dim3(256), 0, s, N, C, Wd, dz2, dz1, save_z,
+                       save_pool, dw1, db1, dw2, db2);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dsum, N, C, S, count, gamma, save,
+                       save_se, dpool, nsum, cb, dgamma, dbeta, 0);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_bn_add_relu_fwd(const float* a3, const float* c3, const float* res, const float* cd, float* out,
+                                   int N, int C, int P, void* stream) {
+    X3D_CHECK_ARG(a3 && c3 && res && out && N > 0 && C > 0 && P > 0);
+    X3D_CHECK_ARG((long long)N * C <= 65535LL * 32768LL);
+    dim3 grid(cdiv(P, EW_TILE), N * C), block(256);
+    X3D_CHECK_ARG(N * C <= 65535);
+    if (P % 4 == 0)
+        hipLaunchKernelGGL(bn_add_relu_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a3, c3, res, cd, out, P);
+    else
+        hipLaunchKernelGGL(bn_add_relu_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a3, c3, res, cd, out, P);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_bn_add_relu_bwd(const float* dout, const float* out, const float* a3, const float* ad, float* g,
+                                   float* partial, float* partial_d, int N, int C, int P, void* stream) {
+    X3D_CHECK_ARG(dout && out && a3 && g && partial && N > 0 && C > 0 && P > 0 && N * C <= 65535);
+    X3D_CHECK_ARG((ad == nullptr) == (partial_d == nullptr));
+    const int tiles = cdiv(P, EW_TILE);
+    dim3 grid(tiles, N * C), block(256);
+    if (P % 4 == 0)
+        hipLaunchKernelGGL(bn_add_relu_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, dout, out, a3, ad, g,
+                           partial, partial_d, P, tiles);
+    else
+        hipLaunchKernelGGL(bn_add_relu_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, dout, out, a3, ad, g,
+                           partial, partial_d, P, tiles);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_bn_relu_pool_fwd(const float* a5, const float* c5, float* pooled, int N, int C, int P,
+                                    void* stream) {
+    X3D_CHECK_ARG(a5 && c5 && pooled && N > 0 && C > 0 && P > 0);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, a5, c5, pooled, P);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_bn_relu_pool_bwd(const float* a5, const float* c5, const float* dpooled, float* g, float* partial,
+                                    int N, int C, int P, void* stream) {
+    X3D_CHECK_ARG(a5 && c5 && dpooled && g && partial && N > 0 && C > 0 && P > 0 && N * C <= 65535);
+    const int tiles = cdiv(P, EW_TILE);
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel, dim3(tiles, N * C), dim3(256), 0, (hipStream_t)stream, a5, c5, dpooled,
+                       g, partial, P, tiles);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_sgd_fused(float* w, const float* g, float* m, size_t n, float lr, float momentum,
+                             float weight_decay, float grad_scale, int first, void* stream) {
+    X3D_CHECK_ARG(w && g && m && n > 0);
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, n, lr,
+                       momentum, weight_decay, grad_scale, first);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}

@@ -1,0 +1,101 @@
+"""ctypes binding of libx3dhip.so (include/x3dhip.h).
+
+The library is mandatory for the product path: ``lib()`` raises if it is missing or if its
+ABI version differs -- there is no CPU or eager-PyTorch fallback behind these ops.
+Tensors are passed as ``tensor.data_ptr()``; the stream as
+``torch.cuda.current_stream().cuda_stream``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libx3dhip.so")
+ABI_VERSION = 1
+
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_Z = ctypes.c_size_t
+
+# name -> (restype, argtypes).  Every symbol include/x3dhip.h declares is listed here;
+# tests/test_abi.py checks the two against each other.
+SIGNATURES = {
+    "x3d_abi_version": (_I, []),
+    "x3d_last_error": (ctypes.c_char_p, []),
+    "x3d_pw_tiles": (_I, [_I]),
+    "x3d_pw_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "x3d_pw_bwd_data": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P]),
+    "x3d_pw_wgrad_groups": (_I, [_I, _I]),
+    "x3d_pw_bwd_weight": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "x3d_reduce_partials": (_I, [_P, _P, _I, _I, _P]),
+    "x3d_dw_tiles": (_I, [_I, _I]),
+    "x3d_dw333_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "x3d_dw_bwd_tiles": (_I, [_I, _I, _I]),
+    "x3d_dw333_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "x3d_stem133_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "x3d_stem_wgrad_groups": (_I, [_I, _I]),
+    "x3d_stem133_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "x3d_dw5t_tiles": (_I, [_I]),
+    "x3d_dw5t_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "x3d_dw5t_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "x3d_finalize_scratch_bytes": (_Z, [_I, _I, _I]),
+    "x3d_bn_fwd_finalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "x3d_bn_eval_coef": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P]),
+    "x3d_se_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "x3d_bn_bwd_finalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "x3d_se_bn_bwd_finalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P,
+                                    _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "x3d_ew_tiles": (_I, [_I]),
+    "x3d_bn_add_relu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "x3d_bn_add_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "x3d_bn_relu_pool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "x3d_bn_relu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "x3d_sgd_fused": (_I, [_P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
+}
+
+_lib = None
+
+
+class X3DHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises X3DHipError when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise X3DHipError(
+            "libx3dhip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C x3d-multigrid_amd/csrc`). The X3D product path has no fallback." % LIB_PATH)
+    h = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise X3DHipError("libx3dhip.so lacks symbol %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    v = h.x3d_abi_version()
+    if v != ABI_VERSION:
+        raise X3DHipError("libx3dhip.so ABI %d != expected %d" % (v, ABI_VERSION))
+    _lib = h
+    return h
+
+
+def check(rc):
+    if rc != 0:
+        raise X3DHipError("libx3dhip: error %d: %s" % (rc, lib().x3d_last_error().decode("utf-8", "replace")))
+
+
+def ptr(t):
+    """data_ptr of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

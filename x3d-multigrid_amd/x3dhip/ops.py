@@ -1,0 +1,292 @@
+"""Tensor-level wrappers over the C ABI (include/x3dhip.h).
+
+PyTorch is used for device memory and streams only: every function below allocates its outputs
+with torch, passes raw pointers to libx3dhip.so on the current HIP stream and returns
+tensors.  There is no fallback: a missing library or a CPU tensor raises.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH, check, ptr  # noqa: F401
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise _lib.X3DHipError("x3dhip ops need CUDA(HIP) tensors; got a CPU tensor "
+                                       "(the product path has no CPU fallback)")
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.X3DHipError("x3dhip ops need contiguous float32 tensors")
+
+
+def out_hw(h, stride):
+    return (h - 1) // 2 + 1 if stride == 2 else h
+
+
+def _f(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+_scratch = {}
+
+
+def scratch(dev, nbytes):
+    """Grow-only per-device scratch for the finalize kernels (fp64 tile sums)."""
+    cur = _scratch.get(dev)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _scratch[dev] = cur
+    return cur
+
+
+def finalize_scratch(dev, N, C, Wd=0):
+    return scratch(dev, _lib.lib().x3d_finalize_scratch_bytes(N, C, max(Wd, 1)))
+
+
+# ----------------------------------------------------------------------------- pointwise
+def pw_fwd(x, w, stride=1, pre=None, pre_act=ACT_NONE, want_stats=True, out=None, partial=None):
+    _need_cuda(x, w, pre)
+    L = _lib.lib()
+    N, Cin, T, H, W = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = out_hw(H, stride), out_hw(W, stride)
+    y = out if out is not None else _f((N, Cout, T, Ho, Wo), x)
+    if want_stats and partial is None:
+        partial = _f((N, Cout, L.x3d_pw_tiles(T * Ho * Wo), 2), x)
+    check(L.x3d_pw_fwd(ptr(x), ptr(w), ptr(y), N, Cin, Cout, T, H, W, stride, ptr(pre), pre_act,
+                       ptr(partial) if want_stats else None, _lib.stream()))
+    return y, (partial if want_stats else None)
+
+
+def pw_bwd_data(g, a, cb, w, x=None, pre=None, pre_act=ACT_NONE, addend=None, addend_stride=1,
+                out=None, partial=None):
+    _need_cuda(g, a, cb, w, x, pre, addend)
+    L = _lib.lib()
+    N, Cout, T, H, W = g.shape
+    Cin = w.shape[1]
+    o = out if out is not None else _f((N, Cin, T, H, W), g)
+    if pre is not None and partial is None:
+        partial = _f((N, Cin, L.x3d_pw_tiles(T * H * W), 2), g)
+    check(L.x3d_pw_bwd_data(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(o), N, Cin, Cout, T, H, W, ptr(x), ptr(pre),
+                            pre_act, ptr(addend), addend_stride, ptr(partial) if pre is not None else None,
+                            _lib.stream()))
+    return o, (partial if pre is not None else None)
+
+
+def reduce_partials(partial, n_out, out=None):
+    L = _lib.lib()
+    groups = partial.shape[0]
+    o = out if out is not None else _f((n_out,), partial)
+    check(L.x3d_reduce_partials(ptr(partial), ptr(o), groups, n_out, _lib.stream()))
+    return o
+
+
+def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, out=None, wpartial=None):
+    _need_cuda(g, a, cb, x, pre)
+    L = _lib.lib()
+    N, Cin, T, H, W = x.shape
+    Cout = g.shape[1]
+    Ho, Wo = out_hw(H, stride), out_hw(W, stride)
+    groups = L.x3d_pw_wgrad_groups(N, T * Ho * Wo)
+    if wpartial is None:
+        wpartial = _f((groups, Cout, Cin), g)
+    check(L.x3d_pw_bwd_weight(ptr(g), ptr(a), ptr(cb), ptr(x), ptr(pre), pre_act, ptr(wpartial), N, Cin, Cout, T,
+                              H, W, stride, _lib.stream()))
+    dw = reduce_partials(wpartial.view(groups, -1), Cout * Cin, out=out)
+    return dw.view(w_shape)
+
+
+# ----------------------------------------------------------------------------- channelwise
+def dw333_fwd(x, w, stride=1, pre=None, pre_act=ACT_RELU, want_stats=True, out=None, partial=None):
+    _need_cuda(x, w, pre)
+    L = _lib.lib()
+    N, C, T, H, W = x.shape
+    Ho, Wo = out_hw(H, stride), out_hw(W, stride)
+    y = out if out is not None else _f((N, C, T, Ho, Wo), x)
+    if want_stats and partial is None:
+        partial = _f((N, C, L.x3d_dw_tiles(Ho, Wo), 2), x)
+    check(L.x3d_dw333_fwd(ptr(x), ptr(w), ptr(y), N, C, T, H, W, stride, ptr(pre), pre_act,
+                          ptr(partial) if want_stats else None, _lib.stream()))
+    return y, (partial if want_stats else None)
+
+
+def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wpartial=None, partial=None,
+              dw_out=None):
+    _need_cuda(g, a, cb, w, x, pre)
+    L = _lib.lib()
+    N, C, T, H, W = x.shape
+    tiles = L.x3d_dw_bwd_tiles(H, W, stride)
+    o = out if out is not None else _f(x.shape, x)
+    if wpartial is None:
+        wpartial = _f((N, C, tiles, 27), x)
+    if partial is None:
+        partial = _f((N, C, tiles, 2), x)
+    check(L.x3d_dw333_bwd(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(x), ptr(pre), pre_act, ptr(o), ptr(wpartial),
+                          ptr(partial), N, C, T, H, W, stride, _lib.stream()))
+    # dW[c][27] = sum over n and tiles.  Reuse the tile reducer: view as [N][C*tiles*27] is not
+    # a plain group sum, so reduce with a strided view: [N*tiles groups] x [C*27]
+    wp = wpartial.permute(0, 2, 1, 3).contiguous().view(N * tiles, C * 27)
+    dw = reduce_partials(wp, C * 27, out=dw_out)
+    return o, dw.view(w.shape), partial
+
+
+# ----------------------------------------------------------------------------- stem
+def stem133_fwd(x, w, out=None):
+    _need_cuda(x, w)
+    L = _lib.lib()
+    N, Cin, T, H, W = x.shape
+    Cout = w.shape[0]
+    y = out if out is not None else _f((N, Cout, T, out_hw(H, 2), out_hw(W, 2)), x)
+    check(L.x3d_stem133_fwd(ptr(x), ptr(w), ptr(y), N, Cin, Cout, T, H, W, _lib.stream()))
+    return y
+
+
+def stem133_bwd_weight(x, dy, w_shape, out=None):
+    _need_cuda(x, dy)
+    L = _lib.lib()
+    N, Cin, T, H, W = x.shape
+    Cout = dy.shape[1]
+    groups = L.x3d_stem_wgrad_groups(N, T)
+    wp = _f((groups, Cout, Cin * 9), x)
+    check(L.x3d_stem133_bwd_weight(ptr(x), ptr(dy), ptr(wp), N, Cin, Cout, T, H, W, _lib.stream()))
+    return reduce_partials(wp.view(groups, -1), Cout * Cin * 9, out=out).view(w_shape)
+
+
+def dw5t_fwd(x, w, want_stats=True, out=None):
+    _need_cuda(x, w)
+    L = _lib.lib()
+    N, C, T, H, W = x.shape
+    y = out if out is not None else _f(x.shape, x)
+    partial = _f((N, C, L.x3d_dw5t_tiles(H * W), 2), x) if want_stats else None
+    check(L.x3d_dw5t_fwd(ptr(x), ptr(w), ptr(y), N, C, T, H * W, ptr(partial), _lib.stream()))
+    return y, partial
+
+
+def dw5t_bwd(g, a, cb, w, x, out=None, dw_out=None):
+    _need_cuda(g, a, cb, w, x)
+    L = _lib.lib()
+    N, C, T, H, W = x.shape
+    tiles = L.x3d_dw5t_tiles(H * W)
+    dx = out if out is not None else _f(x.shape, x)
+    wp = _f((N, C, tiles, 5), x)
+    check(L.x3d_dw5t_bwd(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(x), ptr(dx), ptr(wp), N, C, T, H * W, _lib.stream()))
+    wp2 = wp.permute(0, 2, 1, 3).contiguous().view(N * tiles, C * 5)
+    return dx, reduce_partials(wp2, C * 5, out=dw_out).view(w.shape)
+
+
+# ----------------------------------------------------------------------------- BN / SE
+def bn_fwd_finalize(partial, S, count, gamma, beta, running_mean=None, running_var=None, momentum=0.1,
+                    eps=1e-5, want_nsum=False):
+    L = _lib.lib()
+    N, C, tiles, _ = partial.shape
+    coef = _f((N, C, 2), partial)
+    save = _f((2, S, C), partial)
+    nsum = _f((N, C), partial) if want_nsum else None
+    sc = finalize_scratch(partial.device, N, C)
+    check(L.x3d_bn_fwd_finalize(ptr(partial), N, C, tiles, S, count, ptr(gamma), ptr(beta), ptr(running_mean),
+                                ptr(running_var), momentum, eps, ptr(coef), ptr(save), ptr(nsum), ptr(sc),
+                                _lib.stream()))
+    return coef, save, nsum
+
+
+def bn_eval_coef(running_mean, running_var, gamma, beta, N, eps=1e-5):
+    L = _lib.lib()
+    C = gamma.shape[0]
+    coef = _f((N, C, 2), gamma)
+    check(L.x3d_bn_eval_coef(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, N, C, ptr(coef),
+                             _lib.stream()))
+    return coef
+
+
+def se_fwd(coef, nsum, count, w1, b1, w2, b2):
+    L = _lib.lib()
+    N, C, _ = coef.shape
+    Wd = w1.shape[0]
+    coef_out = _f((N, C, 2), coef)
+    se = _f((N, C), coef)
+    z = _f((N, Wd), coef)
+    pool = _f((N, C), coef)
+    check(L.x3d_se_fwd(ptr(coef), ptr(nsum), N, C, Wd, count, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(coef_out),
+                       ptr(se), ptr(z), ptr(pool), _lib.stream()))
+    return coef_out, se, z, pool
+
+
+def bn_bwd_finalize(partial, S, count, gamma, save, dgamma=None, dbeta=None, accumulate=False):
+    L = _lib.lib()
+    N, C, tiles, _ = partial.shape
+    cb = _f((N, C, 3), partial)
+    if dgamma is None:
+        dgamma, dbeta = _f((C,), partial), _f((C,), partial)
+    sc = finalize_scratch(partial.device, N, C)
+    check(L.x3d_bn_bwd_finalize(ptr(partial), N, C, tiles, S, count, ptr(gamma), ptr(save), ptr(cb), ptr(dgamma),
+                                ptr(dbeta), 1 if accumulate else 0, ptr(sc), _lib.stream()))
+    return cb, dgamma, dbeta
+
+
+def se_bn_bwd_finalize(partial, S, count, gamma, beta, save, nsum, w1, w2, se, z, pool, outs=None):
+    L = _lib.lib()
+    N, C, tiles, _ = partial.shape
+    Wd = w1.shape[0]
+    cb = _f((N, C, 3), partial)
+    if outs is None:
+        outs = dict(dgamma=_f((C,), partial), dbeta=_f((C,), partial), dw1=_f((Wd, C), partial),
+                    db1=_f((Wd,), partial), dw2=_f((C, Wd), partial), db2=_f((C,), partial))
+    sc = finalize_scratch(partial.device, N, C, Wd)
+    check(L.x3d_se_bn_bwd_finalize(ptr(partial), N, C, tiles, S, count, ptr(gamma), ptr(beta), ptr(save), ptr(nsum),
+                                   Wd, ptr(w1), ptr(w2), ptr(se), ptr(z), ptr(pool), ptr(cb), ptr(outs["dgamma"]),
+                                   ptr(outs["dbeta"]), ptr(outs["dw1"]), ptr(outs["db1"]), ptr(outs["dw2"]),
+                                   ptr(outs["db2"]), ptr(sc), _lib.stream()))
+    return cb, outs
+
+
+# ----------------------------------------------------------------------------- elementwise
+def bn_add_relu_fwd(a3, c3, res, cd=None, out=None):
+    _need_cuda(a3, c3, res, cd)
+    L = _lib.lib()
+    N, C = a3.shape[:2]
+    P = a3[0, 0].numel()
+    o = out if out is not None else _f(a3.shape, a3)
+    check(L.x3d_bn_add_relu_fwd(ptr(a3), ptr(c3), ptr(res), ptr(cd), ptr(o), N, C, P, _lib.stream()))
+    return o
+
+
+def bn_add_relu_bwd(dout, out, a3, ad=None, g=None):
+    _need_cuda(dout, out, a3, ad)
+    L = _lib.lib()
+    N, C = a3.shape[:2]
+    P = a3[0, 0].numel()
+    tiles = L.x3d_ew_tiles(P)
+    g = g if g is not None else _f(a3.shape, a3)
+    partial = _f((N, C, tiles, 2), a3)
+    partial_d = _f((N, C, tiles, 2), a3) if ad is not None else None
+    check(L.x3d_bn_add_relu_bwd(ptr(dout), ptr(out), ptr(a3), ptr(ad), ptr(g), ptr(partial), ptr(partial_d), N, C, P,
+                                _lib.stream()))
+    return g, partial, partial_d
+
+
+def bn_relu_pool_fwd(a5, c5):
+    _need_cuda(a5, c5)
+    L = _lib.lib()
+    N, C = a5.shape[:2]
+    P = a5[0, 0].numel()
+    pooled = _f((N, C), a5)
+    check(L.x3d_bn_relu_pool_fwd(ptr(a5), ptr(c5), ptr(pooled), N, C, P, _lib.stream()))
+    return pooled
+
+
+def bn_relu_pool_bwd(a5, c5, dpooled, g=None):
+    _need_cuda(a5, c5, dpooled)
+    L = _lib.lib()
+    N, C = a5.shape[:2]
+    P = a5[0, 0].numel()
+    g = g if g is not None else _f(a5.shape, a5)
+    partial = _f((N, C, L.x3d_ew_tiles(P), 2), a5)
+    check(L.x3d_bn_relu_pool_bwd(ptr(a5), ptr(c5), ptr(dpooled), ptr(g), ptr(partial), N, C, P, _lib.stream()))
+    return g, partial
+
+
+def sgd_fused(w, g, m, lr, momentum=0.9, weight_decay=5e-5, grad_scale=1.0, first=False):
+    _need_cuda(w, g, m)
+    check(_lib.lib().x3d_sgd_fused(ptr(w), ptr(g), ptr(m), w.numel(), lr, momentum, weight_decay, grad_scale,
+                                   1 if first else 0, _lib.stream()))
