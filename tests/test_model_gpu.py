@@ -1,0 +1,134 @@
+"""End-to-end parity of the HIP path (GPU): x3d.generate_model(...) on cuda:0, called exactly
+like the reference model (train_x3d_kinetics_multigrid.py:244-271), against the golden vectors
+produced by the reference itself (tests/golden) and, for tight block-level checks, against the
+CPU oracle on identical inputs.  Criteria: tests/parity.py (1e-3 relative; gradients against
+the reference's fp64 value with its own fp32 noise floor)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import x3d_oracle as xo
+from tests import parity
+from x3dhip import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _build(version, S, dev, seed=0):
+    import x3d
+    net = x3d.generate_model(version, n_classes=400, dropout=0.0, base_bn_splits=S)
+    net.load_state_dict(synthetic.procedural_state_dict(xo.state_template(version, 400, S), seed))
+    return net.to(dev)
+
+
+TRAIN_CASES = ["train_M_2x4x32_s1", "train_M_8x4x64_s2", "train_M_16x2x47_s4", "train_M_2x4x111_s1",
+               "train_M_2x4x158_s2", "train_M_2x8x112_s1", "train_M_8x16x224_s1"]
+
+
+@pytest.mark.parametrize("case", TRAIN_CASES)
+def test_train_step_vs_reference_golden(golden_dir, case):
+    dev = _dev()
+    g = _golden(golden_dir, case)
+    B, T, H, S = [int(v) for v in g["shape"]]
+    net = _build("M", S, dev, int(g["seed"][0]))
+    net.train(True)
+    x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1])).to(dev)
+    y = synthetic.synthetic_labels(B, seed=int(g["seed"][1])).to(dev)
+    logits = net(x)
+    assert logits.shape == (B, 400, 1)
+    loss = torch.nn.CrossEntropyLoss()(logits, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    e_log, e_loss = parity.check_forward(logits.detach().cpu().numpy()[:, :, 0], loss.item(), g)
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
+    rep = parity.check_grads(grads, g, synthetic.gradient_sketch)
+    sd = net.state_dict()
+    parity.check_bn_stats({k: v.cpu().numpy() for k, v in sd.items() if v.ndim}, g)
+    assert int(sd["bn1.split_bn.num_batches_tracked"]) == 1
+    print("\n[%s] logits %.2e loss %.2e | %s" % (case, e_log, e_loss,
+          " ".join("%s=%.2e" % kv for kv in sorted(rep.items()))))
+    # eval after aggregation on the same clip (x3d.py:306-313; train...:203-206)
+    net.train(False)
+    assert net.aggregate_sub_bn_stats() == int(g["n_agg"])
+    sd = net.state_dict()
+    for k in g.files:
+        if k.startswith("agg_rm/"):
+            assert parity.rel(sd[k[7:] + ".bn.running_mean"].cpu().numpy(), g[k]) < parity.RTOL, k
+        if k.startswith("agg_rv/"):
+            assert parity.rel(sd[k[7:] + ".bn.running_var"].cpu().numpy(), g[k]) < parity.RTOL, k
+    with torch.no_grad():
+        ev = net(x)
+    assert parity.rel(ev.cpu().numpy()[:, :, 0], g["eval_logits"]) < parity.RTOL
+
+
+def test_eval_forward_config1_S(golden_dir):
+    """BASELINE config 1: X3D-S eval forward on (2,3,13,160,160)."""
+    dev = _dev()
+    g = _golden(golden_dir, "eval_S_2x13x160")
+    net = _build("S", 1, dev)
+    net.train(False)
+    with torch.no_grad():
+        logits = net(synthetic.synthetic_clips(2, 13, 160, 160).to(dev))
+    assert parity.rel(logits.cpu().numpy()[:, :, 0], g["logits"]) < parity.RTOL
+
+
+@pytest.mark.parametrize("shape", [(4, 4, 40, 2), (2, 2, 31, 1), (8, 4, 18, 4)])
+def test_blocks_tight_vs_oracle(shape):
+    """Module-level parity with identical inputs (SURVEY.md section 4 test pyramid): every kind
+    of bottleneck (SE / no SE, downsample / identity) forward and backward through the HIP
+    schedule against the fp64 oracle fed the SAME block input and upstream gradient, so no
+    ReLU decision of the block INPUT can differ (decisions inside the block still can, between
+    fp32 and fp64): tolerance 2e-5 forward, 1e-3 backward."""
+    from x3dhip import engine
+    dev = _dev()
+    B, T, H, S = shape
+    net = _build("M", S, dev)
+    net.train(True)
+    sd64 = {k: (v.double() if v.is_floating_point() else v)
+            for k, v in synthetic.procedural_state_dict(xo.state_template("M", 400, S), 0).items()}
+    rows = {r[0]: r for r in xo.block_table("M")}
+    g = torch.Generator().manual_seed(5)
+    for name in ["layer1.0", "layer1.1", "layer1.2", "layer2.0", "layer3.3", "layer4.0", "layer4.2"]:
+        p, cin, cm, co, stride, se, ds = rows[name]
+        li, bi = name.split(".")
+        blk = getattr(net, li)[int(bi)]
+        x = torch.relu(torch.randn(B, cin, T, H, H, generator=g, dtype=torch.float64))
+        leaf = {k: v.clone().requires_grad_(True) for k, v in sd64.items() if k.startswith(p + ".") and xo.is_parameter(k)}
+        full = dict(sd64)
+        full.update(leaf)
+        xr = x.clone().requires_grad_(True)
+        out_ref = xo.bottleneck(xr, full, p, stride, se, ds, S, True, None)
+        dout = torch.randn(out_ref.shape, generator=g, dtype=torch.float64)
+        out_ref.backward(dout)
+        ctx = engine.TrunkContext()
+        out, _ = engine._block_forward(blk, x.float().to(dev), None, S, True, ctx)
+        assert parity.rel(out.cpu().numpy(), out_ref.detach().numpy()) < 2e-5, name
+        grads = {}
+        dprev, _ = engine._block_backward(ctx.blocks[0], dout.float().to(dev), grads)
+        assert parity.rel(dprev.cpu().numpy(), xr.grad.numpy()) < 1e-3, name
+        for k, v in leaf.items():
+            mod = blk
+            for part in k[len(p) + 1:].split("."):
+                mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+            e = parity.rel(grads[mod].cpu().numpy().reshape(-1), v.grad.numpy().reshape(-1))
+            assert e < 1e-3, (k, e)
+
+
+def test_batch_not_divisible_by_splits_raises():
+    dev = _dev()
+    net = _build("M", 4, dev)
+    net.train(True)
+    with pytest.raises(ValueError):
+        net(torch.zeros(6, 3, 4, 32, 32, device=dev))

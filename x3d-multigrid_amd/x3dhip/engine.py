@@ -1,0 +1,265 @@
+"""Forward/backward schedule of the X3D trunk over the HIP kernels.
+
+This is the host side of the hot path: it decides which kernel runs on which buffer in what
+order; all arithmetic happens in libx3dhip.so.  The data flow is re-cut relative to the
+reference's module graph (x3d.py:143-171, 316-331) so that every activation tensor is
+touched the minimum number of times:
+
+  forward, per bottleneck
+    conv1  (pw GEMM)  reads x            writes a1 (raw)   + BN1 partial sums in its epilogue
+    conv2  (dw 3x3x3) reads a1 (BN1+ReLU applied on load)  writes a2 (raw) + BN2 partial sums
+    [SE runs on the pooled BN2 statistics: no pass over a2]
+    conv3  (pw GEMM)  reads a2 (BN2*SE + Swish on load)    writes a3 (raw) + BN3 partial sums
+    [downsample: pw GEMM stride 2 on x -> ad (raw) + its BN partial sums]
+    epilogue          out = relu(BN3(a3) + (x | BNd(ad)))
+  backward mirrors it; BN backward is an affine combination  d(raw) = A*g + B*raw + C  with
+  per-(sample, channel) coefficients, applied on load by the consumer conv kernels.
+
+Only raw conv outputs (a1, a2, a3, ad) and block outputs are kept for backward.
+"""
+import torch
+
+from . import ops
+from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH
+
+BN_EPS = 1e-5        # nn.BatchNorm3d defaults used by SubBatchNorm3d (x3d.py:23-25)
+BN_MOMENTUM = 0.1
+
+
+class _BNRef:
+    """Pointers to one SubBatchNorm3d's tensors (x3d.py:9-25)."""
+
+    def __init__(self, mod):
+        self.mod = mod
+
+    @property
+    def gamma(self):
+        return self.mod.weight.data
+
+    @property
+    def beta(self):
+        return self.mod.bias.data
+
+
+def _w2d(p):
+    return p.data.view(p.shape[0], -1)
+
+
+class TrunkContext:
+    """Everything the backward pass needs from one forward pass."""
+
+    def __init__(self):
+        self.blocks = []
+        self.stem = None
+        self.head = None
+
+
+def _bn_train(partial, bn, S, count, want_nsum=False):
+    return ops.bn_fwd_finalize(partial, S, count, bn.weight.data, bn.bias.data,
+                               bn.split_bn.running_mean, bn.split_bn.running_var,
+                               BN_MOMENTUM, BN_EPS, want_nsum=want_nsum)
+
+
+def _bn_eval(bn, N):
+    return ops.bn_eval_coef(bn.bn.running_mean, bn.bn.running_var, bn.weight.data, bn.bias.data, N, BN_EPS)
+
+
+def trunk_forward(model, x, training, ctx=None):
+    """x: float32 [N,3,T,H,W] on the GPU.  Returns pooled features [N, C5] (the input of
+    the head's fc1, x3d.py:331-333).  ctx (TrunkContext) collects what backward needs."""
+    N, _, T, H, W = x.shape
+    S = model.bn1.num_splits
+    if training and N % S != 0:
+        raise ValueError("batch size %d is not divisible by num_splits %d (x3d.py:50)" % (N, S))
+
+    # ---- stem: conv1_s (raw) -> conv1_t (raw + stats) -> bn1+relu applied lazily by consumers
+    a_s = ops.stem133_fwd(x, model.conv1_s.weight.data)
+    a_t, part = ops.dw5t_fwd(a_s, model.conv1_t.weight.data, want_stats=training)
+    P = a_t[0, 0].numel()
+    if training:
+        c0, save0, _ = _bn_train(part, model.bn1, S, P)
+    else:
+        c0, save0 = _bn_eval(model.bn1, N), None
+    if ctx is not None:
+        ctx.stem = dict(x=x, a_s=a_s, a_t=a_t, c0=c0, save0=save0)
+
+    cur_raw, cur_coef = a_t, c0          # lazy: consumers apply relu(c0 * a_t)
+    for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
+        for blk in layer:
+            cur_raw, cur_coef = _block_forward(blk, cur_raw, cur_coef, S, training, ctx)
+
+    # ---- conv5 / bn5 / relu / global average pool
+    a5, p5 = ops.pw_fwd(cur_raw, _w2d(model.conv5.weight), want_stats=training)
+    P5 = a5[0, 0].numel()
+    if training:
+        c5, save5, _ = _bn_train(p5, model.bn5, S, P5)
+    else:
+        c5, save5 = _bn_eval(model.bn5, N), None
+    pooled = ops.bn_relu_pool_fwd(a5, c5)
+    if ctx is not None:
+        ctx.head = dict(x4=cur_raw, a5=a5, c5=c5, save5=save5, S=S)
+    return pooled
+
+
+def _block_forward(blk, x_raw, x_coef, S, training, ctx):
+    N = x_raw.shape[0]
+    pre_act = ACT_RELU if x_coef is not None else ACT_NONE
+    stride = blk.stride
+    a1, p1 = ops.pw_fwd(x_raw, _w2d(blk.conv1.weight), pre=x_coef, pre_act=pre_act, want_stats=training)
+    P1 = a1[0, 0].numel()
+    if training:
+        c1, s1, _ = _bn_train(p1, blk.bn1, S, P1)
+    else:
+        c1, s1 = _bn_eval(blk.bn1, N), None
+    a2, p2 = ops.dw333_fwd(a1, blk.conv2.weight.data, stride=stride, pre=c1, pre_act=ACT_RELU,
+                           want_stats=training or blk.has_se)
+    P2 = a2[0, 0].numel()
+    nsum2 = None
+    if training:
+        c2, s2, nsum2 = _bn_train(p2, blk.bn2, S, P2, want_nsum=blk.has_se)
+    else:
+        c2, s2 = _bn_eval(blk.bn2, N), None
+        if blk.has_se:
+            nsum2 = p2.sum(dim=2)[..., 0].contiguous()   # per-(n,c) sum of raw a2 (tiny tensor)
+    se = None
+    if blk.has_se:
+        c2e, se_v, z, pool = ops.se_fwd(c2, nsum2, P2, _w2d(blk.fc1.weight), blk.fc1.bias.data,
+                                        _w2d(blk.fc2.weight), blk.fc2.bias.data)
+        se = dict(se=se_v, z=z, pool=pool, nsum=nsum2)
+    else:
+        c2e = c2
+    a3, p3 = ops.pw_fwd(a2, _w2d(blk.conv3.weight), pre=c2e, pre_act=ACT_SWISH, want_stats=training)
+    if training:
+        c3, s3, _ = _bn_train(p3, blk.bn3, S, P2)
+    else:
+        c3, s3 = _bn_eval(blk.bn3, N), None
+    ad = cd = sd = None
+    if blk.downsample is not None:
+        ad, pd = ops.pw_fwd(x_raw, _w2d(blk.downsample[0].weight), stride=stride, pre=x_coef, pre_act=pre_act,
+                            want_stats=training)
+        if training:
+            cd, sd, _ = _bn_train(pd, blk.downsample[1], S, P2)
+        else:
+            cd, sd = _bn_eval(blk.downsample[1], N), None
+        out = ops.bn_add_relu_fwd(a3, c3, ad, cd)
+    else:
+        if x_coef is not None:
+            raise RuntimeError("identity residual needs a materialised block input")
+        out = ops.bn_add_relu_fwd(a3, c3, x_raw, None)
+    if ctx is not None:
+        ctx.blocks.append(dict(blk=blk, x_raw=x_raw, x_coef=x_coef, a1=a1, c1=c1, s1=s1, a2=a2, c2e=c2e, s2=s2,
+                               se=se, a3=a3, s3=s3, ad=ad, sd=sd, out=out, S=S))
+    return out, None
+
+
+def trunk_backward(model, ctx, dpooled, grads):
+    """dpooled: [N, C5] gradient w.r.t. trunk_forward's result.  Fills grads[param] = tensor
+    for every trunk parameter (keyed by the Parameter object)."""
+    hd = ctx.head
+    S = hd["S"]
+    a5 = hd["a5"]
+    P5 = a5[0, 0].numel()
+    g5, pp = ops.bn_relu_pool_bwd(a5, hd["c5"], dpooled.contiguous())
+    cb5, dg, db = ops.bn_bwd_finalize(pp, S, P5, model.bn5.weight.data, hd["save5"])
+    grads[model.bn5.weight], grads[model.bn5.bias] = dg, db
+    grads[model.conv5.weight] = ops.pw_bwd_weight(g5, a5, cb5, hd["x4"], model.conv5.weight.shape)
+    dcur, _ = ops.pw_bwd_data(g5, a5, cb5, _w2d(model.conv5.weight))
+    del g5
+
+    pstem = None
+    for rec in reversed(ctx.blocks):
+        dcur, pstem = _block_backward(rec, dcur, grads)
+
+    st = ctx.stem
+    a_t = st["a_t"]
+    P = a_t[0, 0].numel()
+    cb0, dg, db = ops.bn_bwd_finalize(pstem, S, P, model.bn1.weight.data, st["save0"])
+    grads[model.bn1.weight], grads[model.bn1.bias] = dg, db
+    dx_s, dwt = ops.dw5t_bwd(dcur, a_t, cb0, model.conv1_t.weight.data, st["a_s"])
+    grads[model.conv1_t.weight] = dwt
+    grads[model.conv1_s.weight] = ops.stem133_bwd_weight(st["x"], dx_s, model.conv1_s.weight.shape)
+
+
+def _block_backward(rec, dout, grads):
+    blk, S = rec["blk"], rec["S"]
+    a1, a2, a3, ad = rec["a1"], rec["a2"], rec["a3"], rec["ad"]
+    x_raw, x_coef = rec["x_raw"], rec["x_coef"]
+    pre_act = ACT_RELU if x_coef is not None else ACT_NONE
+    P1, P2 = a1[0, 0].numel(), a2[0, 0].numel()
+
+    g3, p3, pd = ops.bn_add_relu_bwd(dout, rec["out"], a3, ad)
+    cb3, dg, db = ops.bn_bwd_finalize(p3, S, P2, blk.bn3.weight.data, rec["s3"])
+    grads[blk.bn3.weight], grads[blk.bn3.bias] = dg, db
+
+    # conv3: weight gradient, then data gradient fused with the swish backward
+    grads[blk.conv3.weight] = ops.pw_bwd_weight(g3, a3, cb3, a2, blk.conv3.weight.shape,
+                                                pre=rec["c2e"], pre_act=ACT_SWISH)
+    ds, ps = ops.pw_bwd_data(g3, a3, cb3, _w2d(blk.conv3.weight), x=a2, pre=rec["c2e"], pre_act=ACT_SWISH)
+    if blk.has_se:
+        se = rec["se"]
+        cb2, o = ops.se_bn_bwd_finalize(ps, S, P2, blk.bn2.weight.data, blk.bn2.bias.data, rec["s2"], se["nsum"],
+                                        _w2d(blk.fc1.weight), _w2d(blk.fc2.weight), se["se"], se["z"], se["pool"])
+        grads[blk.bn2.weight], grads[blk.bn2.bias] = o["dgamma"], o["dbeta"]
+        grads[blk.fc1.weight], grads[blk.fc1.bias] = o["dw1"].view(blk.fc1.weight.shape), o["db1"]
+        grads[blk.fc2.weight], grads[blk.fc2.bias] = o["dw2"].view(blk.fc2.weight.shape), o["db2"]
+    else:
+        cb2, dg, db = ops.bn_bwd_finalize(ps, S, P2, blk.bn2.weight.data, rec["s2"])
+        grads[blk.bn2.weight], grads[blk.bn2.bias] = dg, db
+
+    # conv2 (channelwise): fused data + weight backward, relu backward of bn1 in its epilogue
+    g1, dw2, p1 = ops.dw333_bwd(ds, a2, cb2, blk.conv2.weight.data, a1, stride=blk.stride, pre=rec["c1"],
+                                pre_act=ACT_RELU)
+    del ds
+    grads[blk.conv2.weight] = dw2
+    cb1, dg, db = ops.bn_bwd_finalize(p1, S, P1, blk.bn1.weight.data, rec["s1"])
+    grads[blk.bn1.weight], grads[blk.bn1.bias] = dg, db
+
+    # conv1 (+ downsample branch)
+    grads[blk.conv1.weight] = ops.pw_bwd_weight(g1, a1, cb1, x_raw, blk.conv1.weight.shape, pre=x_coef,
+                                                pre_act=pre_act)
+    if blk.downsample is not None:
+        dsc, dsb = blk.downsample[0], blk.downsample[1]
+        cbd, dg, db = ops.bn_bwd_finalize(pd, S, P2, dsb.weight.data, rec["sd"])
+        grads[dsb.weight], grads[dsb.bias] = dg, db
+        grads[dsc.weight] = ops.pw_bwd_weight(g3, ad, cbd, x_raw, dsc.weight.shape, stride=blk.stride, pre=x_coef,
+                                              pre_act=pre_act)
+        addend, _ = ops.pw_bwd_data(g3, ad, cbd, _w2d(dsc.weight))
+        astride = blk.stride
+    else:
+        addend, astride = g3, 1
+    dprev, pprev = ops.pw_bwd_data(g1, a1, cb1, _w2d(blk.conv1.weight), x=x_raw if x_coef is not None else None,
+                                   pre=x_coef, pre_act=pre_act, addend=addend, addend_stride=astride)
+    return dprev, pprev
+
+
+def trunk_parameters(model):
+    """Trunk parameters in a fixed order (everything except the head's fc1/fc2)."""
+    out = []
+    for name, p in model.named_parameters():
+        if name.startswith("fc1.") or name.startswith("fc2."):
+            continue
+        out.append(p)
+    return out
+
+
+class TrunkFunction(torch.autograd.Function):
+    """autograd node for the whole trunk (same convention as the reference's only custom op,
+    SwishEfficient, x3d.py:71-84: forward(ctx, ...) / backward(ctx, grad))."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        tctx = TrunkContext()
+        pooled = trunk_forward(model, x, True, tctx)
+        ctx.model = model
+        ctx.tctx = tctx
+        ctx.params = params
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        grads = {}
+        trunk_backward(ctx.model, ctx.tctx, dpooled, grads)
+        ctx.tctx = None
+        plist = trunk_parameters(ctx.model)
+        out = [grads[p].view(p.shape) for p in plist]
+        return (None, None) + tuple(out)
