@@ -1,0 +1,258 @@
+"""Headline benchmark: X3D-M training step (forward + loss + backward + fused SGD) at the
+multigrid base shape B=8, T=16, H=W=224 (BASELINE.json configs[1]) on N MI355X GPUs, one
+process per GPU, weak scaling (per-GPU batch fixed), synthetic NCTHW clips resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0): clips/s over the whole job, plus
+  roofline     -- the dominant kernel family (by device time in one instrumented step):
+                  algorithmic bytes (in+out elements of each conv pass) over
+                  its HIP-event-measured duration, vs the 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (stock-PyTorch restatement of the reference) timed on the
+                  host cores on a bounded sample (B=2 of the same shape), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "x3d-multigrid_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_elems_M(T, H):
+    """E(T,H,W) of SURVEY.md 8(d) for X3D-S/M (elements per clip): sum over every Conv3d of
+    in+out elements + 3 x block outputs."""
+    def o(h):
+        return (h - 1) // 2 + 1
+    h = [H]
+    for _ in range(5):
+        h.append(o(h[-1]))
+    S = [T * v * v for v in h]          # S[0]=input res, S[1]=stem res, S[2..5]=stage outputs
+    E = 3 * S[0] + 24 * S[1] + 2 * 24 * S[1]       # conv1_s in+out, conv1_t in+out
+    cin = 24
+    for k, (cm, co, n) in enumerate([(54, 24, 3), (108, 48, 5), (216, 96, 11), (432, 192, 7)]):
+        sp, sk = S[k + 1], S[k + 2]
+        # first block: conv1 (cin->cm @sp), conv2 (cm @sp -> @sk), conv3 (cm->co @sk), downsample (cin @sk sampled -> co @sk)
+        E += (cin + cm) * sp + cm * (sp + sk) + (cm + co) * sk + cin * sp + co * sk
+        E += (n - 1) * ((co + cm) * sk + 2 * cm * sk + (cm + co) * sk)
+        E += 3 * n * co * sk
+        cin = co
+    E += (192 + 432) * S[5] + 432 + 2048
+    return E
+
+
+class KernelTimer:
+    """Brackets every ops.* launch of one eager step with HIP events on the current stream."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.records = []
+        self._orig = {}
+
+    def __enter__(self):
+        for name in ("pw_fwd", "pw_bwd_data", "pw_bwd_weight", "dw333_fwd", "dw333_bwd", "stem133_fwd",
+                     "stem133_bwd_weight", "dw5t_fwd", "dw5t_bwd", "bn_add_relu_fwd", "bn_add_relu_bwd",
+                     "bn_relu_pool_fwd", "bn_relu_pool_bwd", "bn_fwd_finalize", "bn_bwd_finalize", "se_fwd",
+                     "se_bn_bwd_finalize", "sgd_fused"):
+            fn = getattr(self.ops, name)
+            self._orig[name] = fn
+            setattr(self.ops, name, self._wrap(name, fn))
+        return self
+
+    def _wrap(self, name, fn):
+        def inner(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.records.append((name, e0, e1, _alg_bytes(name, a, k, r)))
+            return r
+        return inner
+
+    def __exit__(self, *exc):
+        for name, fn in self._orig.items():
+            setattr(self.ops, name, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, e0, e1, nbytes in self.records:
+            d = agg.setdefault(name, [0.0, 0, 0])
+            d[0] += e0.elapsed_time(e1)
+            d[1] += nbytes
+            d[2] += 1
+        return agg
+
+
+def _alg_bytes(name, a, k, r):
+    """Algorithmic bytes of one launch: 4 B x (input elements + output elements) of the conv /
+    elementwise pass it implements (what the pass must move at minimum)."""
+    n = lambda t: t.numel()
+    try:
+        if name in ("pw_fwd", "dw333_fwd", "dw5t_fwd", "stem133_fwd"):
+            x, y = a[0], (r[0] if isinstance(r, tuple) else r)
+            stride = k.get("stride", 1)
+            xin = n(x) // (stride * stride) if name == "pw_fwd" else n(x)
+            return 4 * (xin + n(y))
+        if name == "pw_bwd_data":
+            return 4 * (n(a[0]) + n(r[0]))
+        if name == "pw_bwd_weight":
+            stride = k.get("stride", 1)
+            return 4 * (n(a[0]) + n(a[3]) // (stride * stride))
+        if name == "dw333_bwd":
+            return 4 * 2 * (n(a[0]) + n(a[4]))          # fused data + weight pass
+        if name == "dw5t_bwd":
+            return 4 * 2 * (n(a[0]) + n(a[4]))
+        if name == "stem133_bwd_weight":
+            return 4 * (n(a[0]) + n(a[1]))
+        if name in ("bn_add_relu_fwd", "bn_add_relu_bwd"):
+            return 4 * 3 * n(a[0])
+        if name in ("bn_relu_pool_fwd", "bn_relu_pool_bwd"):
+            return 4 * n(a[0])
+        if name == "sgd_fused":
+            return 20 * n(a[0])
+    except Exception:
+        pass
+    return 0
+
+
+def cpu_baseline(T, H, sample_B=2, steps=2):
+    """CPU oracle (port of the reference) on the host cores: fwd+bwd on a B=2 sample."""
+    from oracle import x3d_oracle as xo
+    from x3dhip import synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synthetic.procedural_state_dict(xo.state_template("M", 400, 1), 0)
+    x = synthetic.synthetic_clips(sample_B, T, H, H)
+    y = synthetic.synthetic_labels(sample_B)
+    xo.train_step_grads(x, y, sd, "M", 1)         # warm-up
+    ts = []
+    for _ in range(steps):
+        t0 = time.time()
+        xo.train_step_grads(x, y, sd, "M", 1)
+        ts.append(time.time() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    return {"value": round(sample_B / t, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "oracle/x3d_oracle.py fwd+bwd, X3D-M B=%d T=%d H=W=%d fp32, median of %d steps, torch CPU %d threads"
+                      % (sample_B, T, H, steps, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    import x3d
+    from x3dhip import ops, synthetic
+    from x3dhip.trainer import Trainer
+
+    B, T, H = args.batch, args.frames, args.size
+    torch.manual_seed(0)
+    net = x3d.generate_model("M", n_classes=400, dropout=0.5, base_bn_splits=max(1, B // 8)).to(dev).train(True)
+    tr = Trainer(net, lr=0.05, process_group=pg, world_size=world, use_graph=not args.no_graph)
+    x = synthetic.synthetic_clips(B, T, H, H, seed=1234 + rank).to(dev)
+    y = synthetic.synthetic_labels(B, seed=1234 + rank).to(dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = tr.step(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = tdt.item()
+    ms = 1000.0 * dt / args.steps
+    value = world * B * args.steps / dt
+
+    E = algorithmic_elems_M(T, H)
+    step_bytes = B * 3 * 4 * E + 20 * 3794322
+    out = {
+        "metric": "clips/sec X3D-M fwd+bwd+SGD at multigrid base shape (whole job)",
+        "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "X3D-M train step B=%d/GPU T=%d H=W=%d, 400 classes, dropout 0.5, SGD momentum" % (B, T, H),
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "launch": "eager" if args.no_graph else "hipGraph(fwd+bwd) + SGD",
+                   "loss": round(float(loss), 4)},
+        "step_hbm_roofline": {"algorithmic_bytes_per_step": step_bytes,
+                              "achieved_GBs": round(step_bytes / (ms * 1e-3) / 1e9, 1),
+                              "frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+
+    if rank == 0 and not args.no_kernel_timing:
+        # one instrumented eager step: HIP events around every launch, same tensors
+        tr_e = tr
+        tr_e.use_graph = False
+        with KernelTimer(ops) as kt:
+            tr_e.step(x, y)
+        agg = kt.summary()
+        tot = sum(v[0] for v in agg.values())
+        dom = max(agg.items(), key=lambda kv: kv[1][0])
+        name, (tms, nbytes, cnt) = dom
+        ach = nbytes / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": name, "launches_per_step": cnt,
+                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "avg_launch_ms": round(tms / cnt, 4),
+                           "alg_bytes_per_launch": int(nbytes / cnt),
+                           "share_of_step_device_time": round(tms / tot, 3)}
+        out["kernel_breakdown_ms"] = {k: [round(v[0], 3), v[2], round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0]
+                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+    elif world > 1 and not args.no_kernel_timing:
+        pass
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(T, H)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,8 @@
 // BN statistics (sum, sum of squares) are accumulated per thread across the whole T march
 // and leave as one partial per (sample, channel, tile).
 #include "common.h"
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -464,9 +466,18 @@ template <typename K, typename ARGS>
 static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, hipStream_t s) {
     dim3 grid(g.tiles, cdiv(g.C, g.cpb), g.N), block(256);
     if (ldsb > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e != hipSuccess) { x3d_set_error("hipFuncSetAttribute(%zu): %s", ldsb, hipGetErrorString(e)); return X3D_ELAUNCH; }
+        // raise the kernel's dynamic-LDS limit once per (kernel, size) -- not on every launch, so a
+        // launch captured into a hipGraph performs no attribute call
+        static std::mutex mu;
+        static std::map<const void*, size_t> done;
+        std::lock_guard<std::mutex> lk(mu);
+        const void* key = reinterpret_cast<const void*>(kernel);
+        auto it = done.find(key);
+        if (it == done.end() || it->second < ldsb) {
+            hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            if (e != hipSuccess) { x3d_set_error("hipFuncSetAttribute(%zu): %s", ldsb, hipGetErrorString(e)); return X3D_ELAUNCH; }
+            done[key] = ldsb;
+        }
     }
     hipLaunchKernelGGL(kernel, grid, block, ldsb, s, args);
     return X3D_OK;
