@@ -75,7 +75,10 @@ class KernelTimer:
             e0.record()
             r = fn(*a, **k)
             e1.record()
-            self.records.append((name, e0, e1, _alg_bytes(name, a, k, r)))
+            shp = "x".join(map(str, a[0].shape)) if hasattr(a[0], "shape") else ""
+            if name.startswith("pw_"):
+                shp += " w=" + "x".join(map(str, (a[1] if name == "pw_fwd" else a[3]).shape[:2])) if name != "pw_bwd_weight" else " w=" + "x".join(map(str, a[4][:2]))
+            self.records.append((name, e0, e1, _alg_bytes(name, a, k, r), shp))
             return r
         return inner
 
@@ -86,7 +89,10 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, e0, e1, nbytes in self.records:
+        self.launches = []
+        for name, e0, e1, nbytes, shp in self.records:
+            ms_ = e0.elapsed_time(e1)
+            self.launches.append((name, shp, round(ms_, 4), round(nbytes / (ms_ * 1e-3) / 1e9, 1) if ms_ > 0 else 0))
             d = agg.setdefault(name, [0.0, 0, 0])
             d[0] += e0.elapsed_time(e1)
             d[1] += nbytes
@@ -158,6 +164,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write the per-launch HIP-event table (JSON) here")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,6 +237,9 @@ def main():
         with KernelTimer(ops) as kt:
             tr_e.step(x, y)
         agg = kt.summary()
+        if args.dump_launches:
+            with open(args.dump_launches, "w") as f:
+                json.dump(kt.launches, f)
         tot = sum(v[0] for v in agg.values())
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         name, (tms, nbytes, cnt) = dom

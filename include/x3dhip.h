@@ -49,14 +49,16 @@ const char* x3d_last_error(void);
  * downsample[0] :272; conv5 :231) as an fp32 MFMA GEMM  Y[co,p] = sum_ci W[co,ci] * in[ci,p].
  * ---------------------------------------------------------------------------------- */
 
-/* number of position tiles per sample the pw kernels use for `partial` (P = output T*H*W) */
-int x3d_pw_tiles(int P);
+/* number of voxel tiles per sample the pw kernels use for `partial`: N samples, M = channels
+ * of the tensor the partial sums describe (forward: Cout, backward-data: Cin), P = its T*H*W,
+ * dense = 0 for the strided (downsample) forward, else 1 */
+int x3d_pw_tiles(int N, int M, int P, int dense);
 
 /* Forward.  in[ci,p] = act(pre[n,ci,0] * x + pre[n,ci,1]) when pre != NULL (fuses the
  * producer's BN-apply + ReLU, or BN-apply * SE-scale + Swish: x3d.py:147-148,151-160), else x.
  * strideHW in {1,2}: 2 = the downsample conv's (1,2,2) stride (x3d.py:101), x is [N,Cin,T,H,W]
  * and y is [N,Cout,T,Ho,Wo].  partial (may be NULL) receives per-(n,co,tile) {sum y, sum y^2}
- * as float[N][Cout][x3d_pw_tiles(Po)][2] for the BN that follows (x3d.py:51). */
+ * as float[N][Cout][x3d_pw_tiles(N,Cout,Po,strideHW==1)][2] for the BN that follows (x3d.py:51). */
 int x3d_pw_fwd(const float* x, const float* w, float* y,
                int N, int Cin, int Cout, int T, int H, int W, int strideHW,
                const float* pre, int pre_act,
@@ -82,7 +84,7 @@ int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float
 /* Backward-weight: dW[co,ci] = sum_{n,p} dY[co,p] * in[ci,p] with dY and in formed as above
  * (strideHW 2: in is sampled at even (h,w) of x[N,Cin,T,H,W]; g,a are at output resolution).
  * wpartial is float[x3d_pw_wgrad_groups(...)][Cout][Cin]; x3d_reduce_partials sums it. */
-int x3d_pw_wgrad_groups(int N, int P);
+int x3d_pw_wgrad_groups(int N, int P, int Cout, int Cin);
 int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb,
                       const float* x, const float* pre, int pre_act,
                       float* wpartial, int N, int Cin, int Cout, int T, int H, int W,

@@ -21,9 +21,6 @@ namespace {
 enum { IN_RAW = 0, IN_AFFACT = 1, IN_BNBWD = 2 };
 enum { EPI_STATS = 0, EPI_PLAIN = 1, EPI_ACTBWD = 2 };
 
-constexpr int PW_BN = 256;    // voxels per workgroup tile (4 waves x 64)
-constexpr int PW_KC = 32;     // channels per LDS weight chunk
-constexpr int PW_KPAD = 34;   // LDS row stride of the weight chunk
 
 struct PwArgs {
     const float* x;       // IN_RAW / IN_AFFACT: input [N][K][Pin];  IN_BNBWD: upstream grad g [N][K][P]
@@ -47,53 +44,68 @@ struct PwArgs {
     int mblocks, mt_run;  // M blocks per voxel tile; 16-row tiles per block actually used
 };
 
-template <int MT, int IN, int EPI, bool VEC>
+// NT consecutive voxels per lane: NT = 4 -> float4 loads/stores (needs P % 4 == 0, dense input),
+// NT = 1 -> dword accesses (any P, strided gather, and 4x more waves for small-P layers).
+template <int NT> struct VecT;
+template <> struct VecT<4> { typedef float4 type; };
+template <> struct VecT<1> { typedef float type; };
+
+template <int NT>
+__device__ __forceinline__ void vload(const float* p, float (&v)[NT]) {
+    if (NT == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1 % NT] = t.y; v[2 % NT] = t.z; v[3 % NT] = t.w;
+    } else {
+        v[0] = p[0];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void vstore(float* p, const float (&v)[NT]) {
+    if (NT == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % NT], v[2 % NT], v[3 % NT]);
+    else p[0] = v[0];
+}
+
+template <int MT, int NT, int IN, int EPI>
 __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
+    constexpr int PW_KC = 32;     // channels per LDS weight chunk
+    constexpr int PW_KPAD = 34;   // LDS row stride of the weight chunk (conflict-free fragment reads)
     __shared__ float Wl[MT * 16 * PW_KPAD];
     __shared__ float red[4 * MT * 16 * 2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
     const int n = blockIdx.y;
-    const int mb = blockIdx.x % A.mblocks, tile = blockIdx.x / A.mblocks;
+    // block order: the M-blocks of one voxel tile get ids 8 apart, i.e. (round-robin dispatch)
+    // the same XCD, so the activation tile they all read is fetched into that XCD's L2 once
+    const int tlo = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int mb = rest % A.mblocks, tile = (rest / A.mblocks) * 8 + tlo;
+    if (tile >= A.tiles) return;
     const int mt_run = A.mt_run;
     const int m0 = mb * mt_run * 16;
     const int bm = min(mt_run * 16, A.M - m0);   // rows of this block that exist
-    const int p0 = tile * PW_BN + wave * 64 + 4 * r;
+    const int p0 = tile * (64 * NT) + wave * (16 * NT) + NT * r;
     const int K = A.K, P = A.P;
+    const bool pv = p0 < P;                      // NT == 4 implies P % 4 == 0: all-or-nothing
 
-    // per-lane input offsets of its 4 voxels (scalar path / strided gather)
-    int off[4];
-    bool pv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = p0 + j;
-        pv[j] = p < P;
-        if (!VEC) {
-            if (IN != IN_BNBWD && A.strided) {
-                const int hw = A.Ho * A.Wo;
-                const int t = p / hw, rem = p - t * hw;
-                const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
-                off[j] = pv[j] ? (t * A.H + 2 * ho) * A.W + 2 * wo : 0;
-            } else {
-                off[j] = pv[j] ? p : 0;
-            }
-        } else {
-            off[j] = p;
-        }
+    int off = p0;                                // input offset of this lane's first voxel
+    if (NT == 1 && IN != IN_BNBWD && A.strided && pv) {
+        const int hw = A.Ho * A.Wo;
+        const int t = p0 / hw, rem = p0 - t * hw;
+        const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
+        off = (t * A.H + 2 * ho) * A.W + 2 * wo;
     }
 
-    f32x4 acc[MT][4];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (K + 3) / 4;        // k-steps of 4 channels
     const int nchunks = (K + PW_KC - 1) / PW_KC;
 
     // register staging of one half chunk (4 k-steps = 16 channels)
-    float4 rx[4], ra[4];
+    float rx[4][NT], ra[4][NT];
     float c0[4], c1[4], c2[4];
 
     auto load_half = [&](int hc) {
@@ -102,25 +114,11 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
             const int k = hc * 16 + ks * 4 + q;
             const bool kv = k < K;
             const int kc = kv ? k : 0;
-            const float* px = A.x + ((size_t)n * K + kc) * (size_t)A.Pin;
-            if (VEC) {
-                rx[ks] = (kv && pv[0]) ? *reinterpret_cast<const float4*>(px + off[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                rx[ks].x = (kv && pv[0]) ? px[off[0]] : 0.f;
-                rx[ks].y = (kv && pv[1]) ? px[off[1]] : 0.f;
-                rx[ks].z = (kv && pv[2]) ? px[off[2]] : 0.f;
-                rx[ks].w = (kv && pv[3]) ? px[off[3]] : 0.f;
-            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { rx[ks][j] = 0.f; ra[ks][j] = 0.f; }
+            if (kv && pv) vload<NT>(A.x + ((size_t)n * K + kc) * (size_t)A.Pin + off, rx[ks]);
             if (IN == IN_BNBWD) {
-                const float* pa = A.a + ((size_t)n * K + kc) * (size_t)P;
-                if (VEC) {
-                    ra[ks] = (kv && pv[0]) ? *reinterpret_cast<const float4*>(pa + off[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    ra[ks].x = (kv && pv[0]) ? pa[off[0]] : 0.f;
-                    ra[ks].y = (kv && pv[1]) ? pa[off[1]] : 0.f;
-                    ra[ks].z = (kv && pv[2]) ? pa[off[2]] : 0.f;
-                    ra[ks].w = (kv && pv[3]) ? pa[off[3]] : 0.f;
-                }
+                if (kv && pv) vload<NT>(A.a + ((size_t)n * K + kc) * (size_t)P + off, ra[ks]);
                 const float* pc = A.cin + ((size_t)n * K + kc) * 3;
                 c0[ks] = kv ? pc[0] : 0.f;
                 c1[ks] = kv ? pc[1] : 0.f;
@@ -134,25 +132,20 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
         }
     };
 
-    float4 xb[4];
+    float xb[4][NT];
     auto combine_half = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float4 v = rx[ks];
-            if (IN == IN_BNBWD) {
-                const float4 av = ra[ks];
-                v.x = pv[0] ? fmaf(c0[ks], v.x, fmaf(c1[ks], av.x, c2[ks])) : 0.f;
-                v.y = pv[1] ? fmaf(c0[ks], v.y, fmaf(c1[ks], av.y, c2[ks])) : 0.f;
-                v.z = pv[2] ? fmaf(c0[ks], v.z, fmaf(c1[ks], av.z, c2[ks])) : 0.f;
-                v.w = pv[3] ? fmaf(c0[ks], v.w, fmaf(c1[ks], av.w, c2[ks])) : 0.f;
-            } else if (IN == IN_AFFACT) {
-                const bool kv = c2[ks] != 0.f;
-                v.x = (kv && pv[0]) ? act_fwd(fmaf(c0[ks], v.x, c1[ks]), A.in_act) : 0.f;
-                v.y = (kv && pv[1]) ? act_fwd(fmaf(c0[ks], v.y, c1[ks]), A.in_act) : 0.f;
-                v.z = (kv && pv[2]) ? act_fwd(fmaf(c0[ks], v.z, c1[ks]), A.in_act) : 0.f;
-                v.w = (kv && pv[3]) ? act_fwd(fmaf(c0[ks], v.w, c1[ks]), A.in_act) : 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float v = rx[ks][j];
+                if (IN == IN_BNBWD) {
+                    v = pv ? fmaf(c0[ks], v, fmaf(c1[ks], ra[ks][j], c2[ks])) : 0.f;
+                } else if (IN == IN_AFFACT) {
+                    v = (c2[ks] != 0.f && pv) ? act_fwd(fmaf(c0[ks], v, c1[ks]), A.in_act) : 0.f;
+                }
+                xb[ks][j] = v;
             }
-            xb[ks] = v;
         }
     };
 
@@ -180,16 +173,14 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
     auto compute_half = [&](int half) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const float4 b = xb[ks];
             const int kk = half * 16 + ks * 4 + q;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if (mt < mt_run) {
                     const float av = Wl[(mt * 16 + r) * PW_KPAD + kk];
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.x, acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.y, acc[mt][1], 0, 0, 0);
-                    acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.z, acc[mt][2], 0, 0, 0);
-                    acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.w, acc[mt][3], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[ks][j], acc[mt][j], 0, 0, 0);
                 }
             }
         }
@@ -213,18 +204,18 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
     }
 
     // ------------------------------ epilogue ------------------------------
-    int aoff[4];
+    int aoff[NT];
     if (EPI != EPI_STATS && A.addend != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int p = p0 + j;
             if (A.addend_stride == 2) {
                 const int hw = A.H * A.W;
                 const int t = p / hw, rem = p - t * hw;
                 const int h = rem / A.W, w = rem - h * A.W;
-                aoff[j] = (pv[j] && !(h & 1) && !(w & 1)) ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : -1;
+                aoff[j] = (pv && !(h & 1) && !(w & 1)) ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : -1;
             } else {
-                aoff[j] = pv[j] ? p : -1;
+                aoff[j] = pv ? p : -1;
             }
         }
     }
@@ -238,47 +229,39 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
                 const int ml = mt * 16 + 4 * q + e;
                 const int m = m0 + ml;
                 const bool mv = ml < bm;
-                float4 v = make_float4(acc[mt][0][e], acc[mt][1][e], acc[mt][2][e], acc[mt][3][e]);
+                float v[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) v[j] = acc[mt][j][e];
                 float s1 = 0.f, s2 = 0.f;
-                if (mv) {
-                    float* py = A.y + ((size_t)n * A.M + m) * (size_t)P;
+                if (mv && pv) {
+                    float* py = A.y + ((size_t)n * A.M + m) * (size_t)P + p0;
                     if (EPI != EPI_STATS && A.addend != nullptr) {
                         const float* pa = A.addend + ((size_t)n * A.M + m) * (size_t)addP;
-                        if (aoff[0] >= 0) v.x += pa[aoff[0]];
-                        if (aoff[1] >= 0) v.y += pa[aoff[1]];
-                        if (aoff[2] >= 0) v.z += pa[aoff[2]];
-                        if (aoff[3] >= 0) v.w += pa[aoff[3]];
+                        if (A.addend_stride == 1 && NT == 4) {
+                            float t4[NT];
+                            vload<NT>(pa + p0, t4);
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) v[j] += t4[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) if (aoff[j] >= 0) v[j] += pa[aoff[j]];
+                        }
                     }
                     if (EPI == EPI_ACTBWD) {
-                        const float* px = A.ex + ((size_t)n * A.M + m) * (size_t)P;
                         const float sc = A.ecoef[((size_t)n * A.M + m) * 2], sh = A.ecoef[((size_t)n * A.M + m) * 2 + 1];
-                        float4 xv;
-                        if (VEC) {
-                            xv = pv[0] ? *reinterpret_cast<const float4*>(px + p0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        } else {
-                            xv.x = pv[0] ? px[p0] : 0.f;
-                            xv.y = pv[1] ? px[p0 + 1] : 0.f;
-                            xv.z = pv[2] ? px[p0 + 2] : 0.f;
-                            xv.w = pv[3] ? px[p0 + 3] : 0.f;
+                        float xv[NT];
+                        vload<NT>(A.ex + ((size_t)n * A.M + m) * (size_t)P + p0, xv);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            v[j] = v[j] * act_bwd(fmaf(sc, xv[j], sh), A.e_act);
+                            s1 += v[j];
+                            s2 = fmaf(v[j], xv[j], s2);
                         }
-                        v.x = pv[0] ? v.x * act_bwd(fmaf(sc, xv.x, sh), A.e_act) : 0.f;
-                        v.y = pv[1] ? v.y * act_bwd(fmaf(sc, xv.y, sh), A.e_act) : 0.f;
-                        v.z = pv[2] ? v.z * act_bwd(fmaf(sc, xv.z, sh), A.e_act) : 0.f;
-                        v.w = pv[3] ? v.w * act_bwd(fmaf(sc, xv.w, sh), A.e_act) : 0.f;
-                        s1 = (v.x + v.y) + (v.z + v.w);
-                        s2 = fmaf(v.x, xv.x, fmaf(v.y, xv.y, fmaf(v.z, xv.z, v.w * xv.w)));
                     } else if (EPI == EPI_STATS) {
-                        s1 = (v.x + v.y) + (v.z + v.w);
-                        s2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
                     }
-                    if (VEC) {
-                        if (pv[0]) *reinterpret_cast<float4*>(py + p0) = v;
-                    } else {
-                        if (pv[0]) py[p0] = v.x;
-                        if (pv[1]) py[p0 + 1] = v.y;
-                        if (pv[2]) py[p0 + 2] = v.z;
-                        if (pv[3]) py[p0 + 3] = v.w;
-                    }
+                    vstore<NT>(py, v);
                 }
                 if (EPI != EPI_PLAIN) {
                     s1 = row16_sum(s1);
@@ -303,36 +286,48 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
     }
 }
 
+// One decision function for kernel variant and tile count (the caller sizes `partial` with it).
+static void pw_plan(int N, int M, int P, bool dense, int* nt, int* tiles, int* mblocks, int* mt_run) {
+    const int mtiles = cdiv(M, 16);
+    *mblocks = cdiv(mtiles, 4);
+    *mt_run = cdiv(mtiles, *mblocks);
+    int v = (dense && (P % 4 == 0)) ? 4 : 1;
+    if (v == 4) {
+        const long long wgs = (long long)cdiv(P, 256) * N * (*mblocks);
+        if (wgs < 1024) v = 1;      // small-P layers: 16 voxels per wave fills the chip (4x the waves)
+    }
+    *nt = v;
+    *tiles = cdiv(P, 64 * v);
+}
+
 template <int IN, int EPI>
 int launch_pw(PwArgs& A, hipStream_t s) {
-    const int mtiles = cdiv(A.M, 16);
-    const int mblocks = cdiv(mtiles, 8);
-    const int mt_run = cdiv(mtiles, mblocks);
-    A.mblocks = mblocks;
-    A.mt_run = mt_run;
-    A.tiles = cdiv(A.P, PW_BN);
-    const bool vec = (A.P % 4 == 0) && (A.Pin % 4 == 0) && !A.strided;
-    dim3 grid(A.tiles * mblocks, A.N), block(256);
-    if (mt_run <= 4) {
-        if (vec) hipLaunchKernelGGL((pw_kernel<4, IN, EPI, true>), grid, block, 0, s, A);
-        else hipLaunchKernelGGL((pw_kernel<4, IN, EPI, false>), grid, block, 0, s, A);
+    int nt;
+    pw_plan(A.N, A.M, A.P, !A.strided && (A.Pin % 4 == 0), &nt, &A.tiles, &A.mblocks, &A.mt_run);
+    dim3 grid(cdiv(A.tiles, 8) * 8 * A.mblocks, A.N), block(256);
+    if (A.mt_run <= 2) {
+        if (nt == 4) hipLaunchKernelGGL((pw_kernel<2, 4, IN, EPI>), grid, block, 0, s, A);
+        else hipLaunchKernelGGL((pw_kernel<2, 1, IN, EPI>), grid, block, 0, s, A);
     } else {
-        if (vec) hipLaunchKernelGGL((pw_kernel<8, IN, EPI, true>), grid, block, 0, s, A);
-        else hipLaunchKernelGGL((pw_kernel<8, IN, EPI, false>), grid, block, 0, s, A);
+        if (nt == 4) hipLaunchKernelGGL((pw_kernel<4, 4, IN, EPI>), grid, block, 0, s, A);
+        else hipLaunchKernelGGL((pw_kernel<4, 1, IN, EPI>), grid, block, 0, s, A);
     }
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
 
 // ---------------------------------------------------------------------------------------
-// Backward-weight: dW[co][ci] = sum_{n,p} dY[co][p] * in[ci][p].
-// Each workgroup owns a 64x64 block of dW and a strided set of 128-voxel tiles; both
-// operand tiles are staged in LDS as [channel][132] (built on the fly from g/a/x with the
-// BN-backward combine and the forward prologue), each wave accumulates a 2x2 grid of 16x16
-// MFMA tiles (K index = voxel), one ds_read_b128 feeding 4 MFMA steps.
+// Backward-weight: dW[co][ci] = sum_{n,p} dY[co][p] * in[ci][p]   (K index = voxel).
+// No LDS staging: with the voxel index on the MFMA K dimension, lane (r = lane & 15,
+// q = lane >> 4) of a 16x16x4 MFMA needs channel row r at voxels 4q..4q+3 of a 16-voxel step,
+// which is exactly one float4 per lane straight from HBM (64 B contiguous per row and step;
+// a wave walks 128 consecutive voxels = whole 512-B row runs).  Every wave owns a private set
+// of 128-voxel units and the whole (co-block x ci-block) of dW in its accumulators; the BN
+// backward combine (dY = cb0*g + cb1*a + cb2) and the forward prologue (act(pre*x+pre)) are
+// applied in registers.  The next step's loads are issued before the current step's MFMAs.
+// Waves are summed through LDS in fixed order; one partial per workgroup goes to HBM.
 // ---------------------------------------------------------------------------------------
-constexpr int WG_PT = 128;
-constexpr int WG_LD = 132;
+constexpr int WG_UNIT = 128;   // voxels per work unit (8 MFMA steps of 16)
 
 struct WgArgs {
     const float* g; const float* a; const float* cb;      // [N][Co][P], [N][Co][P], [N][Co][3]
@@ -340,140 +335,219 @@ struct WgArgs {
     float* wpartial;                                       // [groups][Co][Ci]
     int N, Ci, Co, P; long long Pin;
     int strided, T, H, W, Ho, Wo;
-    int groups, tiles_per_sample, cob, cib;
+    int groups, units_per_sample, cob, cib, ct_run, it_run;
 };
 
+template <int CT, int IT, bool VEC>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs A) {
-    __shared__ __attribute__((aligned(16))) float Ld[64 * WG_LD];
-    __shared__ __attribute__((aligned(16))) float Lx[64 * WG_LD];
+    __shared__ float red[4 * IT * 4 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
     const int blk = blockIdx.y;
-    const int co0 = (blk / A.cib) * 64, ci0 = (blk % A.cib) * 64;
-    const int wr = wave >> 1, wc = wave & 1;     // wave owns co tiles {2wr, 2wr+1} x ci tiles {2wc, 2wc+1}
+    const int co0 = (blk / A.cib) * (A.ct_run * 16), ci0 = (blk % A.cib) * (A.it_run * 16);
+    const int ct_run = A.ct_run, it_run = A.it_run;
+    const int P = A.P;
 
-    f32x4 acc[2][2];
+    f32x4 acc[CT][IT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < IT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int total_tiles = A.N * A.tiles_per_sample;
-    const bool vecd = (A.P % 4 == 0);
-    const bool vecx = vecd && !A.strided && (A.Pin % 4 == 0);
+    // rows of this lane
+    int co[CT], ci[IT];
+    bool cov[CT], civ[IT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) { co[i] = co0 + 16 * i + r; cov[i] = (i < ct_run) && co[i] < A.Co; if (!cov[i]) co[i] = 0; }
+#pragma unroll
+    for (int j = 0; j < IT; ++j) { ci[j] = ci0 + 16 * j + r; civ[j] = (j < it_run) && ci[j] < A.Ci; if (!civ[j]) ci[j] = 0; }
 
-    for (int tl = blockIdx.x; tl < total_tiles; tl += A.groups) {
-        const int n = tl / A.tiles_per_sample, pt = (tl - n * A.tiles_per_sample) * WG_PT;
-        __syncthreads();
-        // stage dY tile: 64 rows x 128 voxels = 2048 float4 -> 8 per thread
-        for (int idx = tid; idx < 64 * 32; idx += 256) {
-            const int row = idx >> 5, c4 = (idx & 31) * 4;
-            const int co = co0 + row, p = pt + c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < A.Co && p < A.P) {
-                const size_t base = ((size_t)n * A.Co + co) * (size_t)A.P + p;
-                const float* cb = A.cb + ((size_t)n * A.Co + co) * 3;
-                const float k0 = cb[0], k1 = cb[1], k2 = cb[2];
-                if (vecd) {
-                    const float4 gv = *reinterpret_cast<const float4*>(A.g + base);
-                    const float4 av = *reinterpret_cast<const float4*>(A.a + base);
-                    v.x = fmaf(k0, gv.x, fmaf(k1, av.x, k2));
-                    v.y = fmaf(k0, gv.y, fmaf(k1, av.y, k2));
-                    v.z = fmaf(k0, gv.z, fmaf(k1, av.z, k2));
-                    v.w = fmaf(k0, gv.w, fmaf(k1, av.w, k2));
+    const int total_units = A.N * A.units_per_sample;
+    const int gw = blockIdx.x * 4 + wave, GW = A.groups * 4;
+
+    float4 ng[CT], na[CT], nx[IT];     // next step's raw loads
+
+    auto issue = [&](int n, int p) {   // p = first voxel of this lane's float4
+        const bool pin = p < P;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            if (i < ct_run) {
+                const size_t base = ((size_t)n * A.Co + co[i]) * (size_t)P + p;
+                if (VEC) {
+                    ng[i] = (cov[i] && pin) ? *reinterpret_cast<const float4*>(A.g + base) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    na[i] = (cov[i] && pin) ? *reinterpret_cast<const float4*>(A.a + base) : make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
-                    float t4[4];
+                    float tg[4], ta[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        t4[j] = (p + j < A.P) ? fmaf(k0, A.g[base + j], fmaf(k1, A.a[base + j], k2)) : 0.f;
-                    v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = cov[i] && (p + e < P);
+                        tg[e] = ok ? A.g[base + e] : 0.f;
+                        ta[e] = ok ? A.a[base + e] : 0.f;
+                    }
+                    ng[i] = make_float4(tg[0], tg[1], tg[2], tg[3]);
+                    na[i] = make_float4(ta[0], ta[1], ta[2], ta[3]);
                 }
             }
-            *reinterpret_cast<float4*>(&Ld[row * WG_LD + c4]) = v;
         }
-        for (int idx = tid; idx < 64 * 32; idx += 256) {
-            const int row = idx >> 5, c4 = (idx & 31) * 4;
-            const int ci = ci0 + row, p = pt + c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < A.Ci && p < A.P) {
-                const float* px = A.x + ((size_t)n * A.Ci + ci) * (size_t)A.Pin;
-                float t4[4];
-                if (vecx) {
-                    const float4 xv = *reinterpret_cast<const float4*>(px + p);
-                    t4[0] = xv.x; t4[1] = xv.y; t4[2] = xv.z; t4[3] = xv.w;
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int pp = p + j;
-                        float xv = 0.f;
-                        if (pp < A.P) {
+        for (int j = 0; j < IT; ++j) {
+            if (j < it_run) {
+                const float* px = A.x + ((size_t)n * A.Ci + ci[j]) * (size_t)A.Pin;
+                if (VEC) {
+                    nx[j] = (civ[j] && pin) ? *reinterpret_cast<const float4*>(px + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    float tx[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int pp = p + e;
+                        float v = 0.f;
+                        if (civ[j] && pp < P) {
                             if (A.strided) {
                                 const int hw = A.Ho * A.Wo;
                                 const int t = pp / hw, rem = pp - t * hw;
                                 const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
-                                xv = px[(size_t)(t * A.H + 2 * ho) * A.W + 2 * wo];
+                                v = px[(size_t)(t * A.H + 2 * ho) * A.W + 2 * wo];
                             } else {
-                                xv = px[pp];
+                                v = px[pp];
                             }
                         }
-                        t4[j] = xv;
+                        tx[e] = v;
+                    }
+                    nx[j] = make_float4(tx[0], tx[1], tx[2], tx[3]);
+                }
+            }
+        }
+    };
+
+    for (int u = gw; u < total_units; u += GW) {
+        const int n = u / A.units_per_sample, pu = (u - n * A.units_per_sample) * WG_UNIT;
+        // per-sample row constants
+        float k0[CT], k1[CT], k2[CT], sc[IT], sh[IT];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const float* cb = A.cb + ((size_t)n * A.Co + co[i]) * 3;
+            k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
+        }
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            sc[j] = 1.f; sh[j] = 0.f;
+            if (A.pre != nullptr) { sc[j] = A.pre[((size_t)n * A.Ci + ci[j]) * 2]; sh[j] = A.pre[((size_t)n * A.Ci + ci[j]) * 2 + 1]; }
+        }
+        issue(n, pu + 4 * q);
+#pragma unroll 1
+        for (int st = 0; st < WG_UNIT / 16; ++st) {
+            const int p = pu + st * 16 + 4 * q;
+            float4 dy[CT], xin[IT];
+            bool pv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[e] = (p + e) < P;
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                dy[i].x = (cov[i] && pv[0]) ? fmaf(k0[i], ng[i].x, fmaf(k1[i], na[i].x, k2[i])) : 0.f;
+                dy[i].y = (cov[i] && pv[1]) ? fmaf(k0[i], ng[i].y, fmaf(k1[i], na[i].y, k2[i])) : 0.f;
+                dy[i].z = (cov[i] && pv[2]) ? fmaf(k0[i], ng[i].z, fmaf(k1[i], na[i].z, k2[i])) : 0.f;
+                dy[i].w = (cov[i] && pv[3]) ? fmaf(k0[i], ng[i].w, fmaf(k1[i], na[i].w, k2[i])) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                if (A.pre != nullptr) {
+                    xin[j].x = (civ[j] && pv[0]) ? act_fwd(fmaf(sc[j], nx[j].x, sh[j]), A.pre_act) : 0.f;
+                    xin[j].y = (civ[j] && pv[1]) ? act_fwd(fmaf(sc[j], nx[j].y, sh[j]), A.pre_act) : 0.f;
+                    xin[j].z = (civ[j] && pv[2]) ? act_fwd(fmaf(sc[j], nx[j].z, sh[j]), A.pre_act) : 0.f;
+                    xin[j].w = (civ[j] && pv[3]) ? act_fwd(fmaf(sc[j], nx[j].w, sh[j]), A.pre_act) : 0.f;
+                } else {
+                    xin[j] = nx[j];
+                }
+            }
+            if (st + 1 < WG_UNIT / 16) issue(n, p + 16);      // prefetch the next step
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                if (i < ct_run) {
+#pragma unroll
+                    for (int j = 0; j < IT; ++j) {
+                        if (j < it_run) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[i].x, xin[j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[i].y, xin[j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[i].z, xin[j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[i].w, xin[j].w, acc[i][j], 0, 0, 0);
+                        }
                     }
                 }
-                if (A.pre != nullptr) {
-                    const float sc = A.pre[((size_t)n * A.Ci + ci) * 2], sh = A.pre[((size_t)n * A.Ci + ci) * 2 + 1];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) t4[j] = (p + j < A.P) ? act_fwd(fmaf(sc, t4[j], sh), A.pre_act) : 0.f;
-                }
-                v = make_float4(t4[0], t4[1], t4[2], t4[3]);
             }
-            *reinterpret_cast<float4*>(&Lx[row * WG_LD + c4]) = v;
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int kk = 0; kk < WG_PT / 16; ++kk) {
-            float4 av[2], bv[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                av[i] = *reinterpret_cast<const float4*>(&Ld[((2 * wr + i) * 16 + r) * WG_LD + kk * 16 + 4 * q]);
-                bv[i] = *reinterpret_cast<const float4*>(&Lx[((2 * wc + i) * 16 + r) * WG_LD + kk * 16 + 4 * q]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
-                }
         }
     }
+
+    // sum the 4 waves (fixed order) and write this workgroup's partial.
     // D[i = co][j = ci]: lane (q, r), reg e -> co = tile*16 + 4q + e, ci = tile*16 + r
     float* out = A.wpartial + (size_t)blockIdx.x * A.Co * A.Ci;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CT; ++i) {
+        if (i < ct_run) {
+            __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < IT; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = co0 + (2 * wr + i) * 16 + 4 * q + e;
-                const int ci = ci0 + (2 * wc + j) * 16 + r;
-                if (co < A.Co && ci < A.Ci) out[(size_t)co * A.Ci + ci] = acc[i][j][e];
+                for (int e = 0; e < 4; ++e) red[((wave * IT + j) * 4 + e) * 64 + lane] = acc[i][j][e];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int j = 0; j < IT; ++j) {
+                    if (j < it_run) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float s = (red[((0 * IT + j) * 4 + e) * 64 + lane] + red[((1 * IT + j) * 4 + e) * 64 + lane]) +
+                                            (red[((2 * IT + j) * 4 + e) * 64 + lane] + red[((3 * IT + j) * 4 + e) * 64 + lane]);
+                            const int oc = co0 + 16 * i + 4 * q + e, ic = ci0 + 16 * j + r;
+                            if (oc < A.Co && ic < A.Ci) out[(size_t)oc * A.Ci + ic] = s;
+                        }
+                    }
+                }
             }
+        }
+    }
+}
+
+static void wgrad_plan(int N, int P, int Co, int Ci, int* groups, int* cob, int* cib, int* ct_run, int* it_run) {
+    const int cot = cdiv(Co, 16), cit = cdiv(Ci, 16);
+    *cob = cdiv(cot, 4); *cib = cdiv(cit, 4);
+    *ct_run = cdiv(cot, *cob); *it_run = cdiv(cit, *cib);
+    const int units = N * cdiv(P, WG_UNIT);
+    int g = cdiv(units, 8);                       // >= 2 units per wave when there is enough work
+    const int cap = 1024 / ((*cob) * (*cib)) > 64 ? 1024 / ((*cob) * (*cib)) : 64;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    *groups = g;
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
                                                               float* __restrict__ out, int groups, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    // 64 outputs per block; the 4 waves take interleaved quarters of the groups (each load is a
+    // 256-B coalesced row segment); fixed summation order -> bitwise reproducible
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     double s = 0.0;
-    for (int g = 0; g < groups; ++g) s += (double)partial[(size_t)g * n + i];
-    out[i] = (float)s;
+    if (i < n) {
+        int g = wave;
+        for (; g + 12 < groups; g += 16) {
+            const float v0 = partial[(size_t)g * n + i], v1 = partial[(size_t)(g + 4) * n + i];
+            const float v2 = partial[(size_t)(g + 8) * n + i], v3 = partial[(size_t)(g + 12) * n + i];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; g < groups; g += 4) s += (double)partial[(size_t)g * n + i];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && i < n) out[i] = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 }  // namespace
 
-extern "C" int x3d_pw_tiles(int P) { return cdiv(P, PW_BN); }
+extern "C" int x3d_pw_tiles(int N, int M, int P, int dense) {
+    int nt, tiles, mb, mt;
+    pw_plan(N, M, P, dense != 0, &nt, &tiles, &mb, &mt);
+    return tiles;
+}
 
 extern "C" int x3d_pw_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout, int T, int H,
                           int W, int strideHW, const float* pre, int pre_act, float* partial, void* stream) {
@@ -512,9 +586,10 @@ extern "C" int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, 
     return launch_pw<IN_BNBWD, EPI_PLAIN>(A, s);
 }
 
-extern "C" int x3d_pw_wgrad_groups(int N, int P) {
-    const int tiles = N * cdiv(P, WG_PT);
-    return tiles < 512 ? tiles : 512;
+extern "C" int x3d_pw_wgrad_groups(int N, int P, int Cout, int Cin) {
+    int g, cob, cib, ct, it;
+    wgrad_plan(N, P, Cout, Cin, &g, &cob, &cib, &ct, &it);
+    return g;
 }
 
 extern "C" int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb, const float* x,
@@ -528,19 +603,29 @@ extern "C" int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb
     A.g = g; A.a = a; A.cb = cb; A.x = x; A.pre = pre; A.pre_act = pre_act; A.wpartial = wpartial;
     A.N = N; A.Ci = Cin; A.Co = Cout; A.P = T * Ho * Wo; A.Pin = (long long)T * H * W;
     A.strided = strideHW == 2; A.T = T; A.H = H; A.W = W; A.Ho = Ho; A.Wo = Wo;
-    A.tiles_per_sample = cdiv(A.P, WG_PT);
-    A.groups = x3d_pw_wgrad_groups(N, A.P);
-    A.cob = cdiv(Cout, 64); A.cib = cdiv(Cin, 64);
+    A.units_per_sample = cdiv(A.P, WG_UNIT);
+    wgrad_plan(N, A.P, Cout, Cin, &A.groups, &A.cob, &A.cib, &A.ct_run, &A.it_run);
     X3D_CHECK_ARG(A.cob * A.cib <= 65535);
     dim3 grid(A.groups, A.cob * A.cib), block(256);
-    hipLaunchKernelGGL(pw_wgrad_kernel, grid, block, 0, (hipStream_t)stream, A);
+    const bool vec = (A.P % 4 == 0) && !A.strided && (A.Pin % 4 == 0);
+    hipStream_t s = (hipStream_t)stream;
+#define WG_LAUNCH(CT_, IT_)                                                                         \
+    do {                                                                                            \
+        if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<CT_, IT_, true>), grid, block, 0, s, A);        \
+        else hipLaunchKernelGGL((pw_wgrad_kernel<CT_, IT_, false>), grid, block, 0, s, A);           \
+    } while (0)
+    if (A.ct_run <= 2 && A.it_run <= 2) WG_LAUNCH(2, 2);
+    else if (A.ct_run <= 2) WG_LAUNCH(2, 4);
+    else if (A.it_run <= 2) WG_LAUNCH(4, 2);
+    else WG_LAUNCH(4, 4);
+#undef WG_LAUNCH
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
 
 extern "C" int x3d_reduce_partials(const float* partial, float* out, int groups, int n, void* stream) {
     X3D_CHECK_ARG(partial && out && groups > 0 && n > 0);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream,
                        partial, out, groups, n);
     X3D_LAUNCH_CHECK();
     return X3D_OK;

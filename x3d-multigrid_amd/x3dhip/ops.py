@@ -53,7 +53,7 @@ def pw_fwd(x, w, stride=1, pre=None, pre_act=ACT_NONE, want_stats=True, out=None
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
     y = out if out is not None else _f((N, Cout, T, Ho, Wo), x)
     if want_stats and partial is None:
-        partial = _f((N, Cout, L.x3d_pw_tiles(T * Ho * Wo), 2), x)
+        partial = _f((N, Cout, L.x3d_pw_tiles(N, Cout, T * Ho * Wo, 1 if stride == 1 else 0), 2), x)
     check(L.x3d_pw_fwd(ptr(x), ptr(w), ptr(y), N, Cin, Cout, T, H, W, stride, ptr(pre), pre_act,
                        ptr(partial) if want_stats else None, _lib.stream()))
     return y, (partial if want_stats else None)
@@ -67,7 +67,7 @@ def pw_bwd_data(g, a, cb, w, x=None, pre=None, pre_act=ACT_NONE, addend=None, ad
     Cin = w.shape[1]
     o = out if out is not None else _f((N, Cin, T, H, W), g)
     if pre is not None and partial is None:
-        partial = _f((N, Cin, L.x3d_pw_tiles(T * H * W), 2), g)
+        partial = _f((N, Cin, L.x3d_pw_tiles(N, Cin, T * H * W, 1), 2), g)
     check(L.x3d_pw_bwd_data(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(o), N, Cin, Cout, T, H, W, ptr(x), ptr(pre),
                             pre_act, ptr(addend), addend_stride, ptr(partial) if pre is not None else None,
                             _lib.stream()))
@@ -88,7 +88,7 @@ def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, ou
     N, Cin, T, H, W = x.shape
     Cout = g.shape[1]
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
-    groups = L.x3d_pw_wgrad_groups(N, T * Ho * Wo)
+    groups = L.x3d_pw_wgrad_groups(N, T * Ho * Wo, Cout, Cin)
     if wpartial is None:
         wpartial = _f((groups, Cout, Cin), g)
     check(L.x3d_pw_bwd_weight(ptr(g), ptr(a), ptr(cb), ptr(x), ptr(pre), pre_act, ptr(wpartial), N, Cin, Cout, T,
