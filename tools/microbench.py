@@ -1,0 +1,67 @@
+"""Micro-benchmark of single kernels at the X3D-M layer shapes (for rocprofv3 --pmc runs)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "x3d-multigrid_amd"))
+import torch  # noqa: E402
+from x3dhip import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "pw_l4"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+
+
+def t(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1000
+
+
+cases = {
+    "pw_l4": (8, 432, 192, 16, 7, 7),
+    "pw_l4b": (8, 192, 432, 16, 7, 7),
+    "pw_l3": (8, 216, 96, 16, 14, 14),
+    "pw_l3b": (8, 96, 216, 16, 14, 14),
+    "pw_l2": (8, 108, 48, 16, 28, 28),
+    "pw_l1": (8, 24, 54, 16, 56, 56),
+    "pw_l1b": (8, 54, 24, 16, 56, 56),
+    "pw_l10": (8, 24, 54, 16, 112, 112),
+}
+if which.startswith("pw"):
+    N, Ci, Co, T, H, W = cases[which]
+    x = torch.randn(N, Ci, T, H, W, device=dev)
+    w = torch.randn(Co, Ci, device=dev) / Ci ** 0.5
+    pre = torch.rand(N, Ci, 2, device=dev)
+    y = torch.empty(N, Co, T, H, W, device=dev)
+    us = t(lambda: ops.pw_fwd(x, w, pre=pre, pre_act=2, out=y))
+    fl = 2.0 * N * Ci * Co * T * H * W
+    by = 4.0 * N * (Ci + Co) * T * H * W
+    print("%s fwd(affine+swish): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
+    us = t(lambda: ops.pw_fwd(x, w, out=y))
+    print("%s fwd(raw): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
+elif which.startswith("dw"):
+    shapes = {"dw_l1": (8, 54, 16, 56, 56, 1), "dw_l10": (8, 54, 16, 112, 112, 2), "dw_l2": (8, 108, 16, 28, 28, 1),
+              "dw_l3": (8, 216, 16, 14, 14, 1), "dw_l4": (8, 432, 16, 7, 7, 1)}
+    N, C, T, H, W, s = shapes[which]
+    x = torch.randn(N, C, T, H, W, device=dev)
+    w = torch.randn(C, 1, 3, 3, 3, device=dev)
+    pre = torch.rand(N, C, 2, device=dev)
+    us = t(lambda: ops.dw333_fwd(x, w, stride=s, pre=pre))
+    Ho = (H - 1) // s + 1
+    by = 4.0 * N * C * T * (H * W + Ho * Ho)
+    print("%s fwd: %.1f us  %.0f GB/s" % (which, us, by / us / 1e3))
+    y, _ = ops.dw333_fwd(x, w, stride=s, pre=pre)
+    g = torch.randn_like(y)
+    cb = torch.rand(N, C, 3, device=dev)
+    us = t(lambda: ops.dw333_bwd(g, y, cb, w, x, stride=s, pre=pre))
+    print("%s bwd: %.1f us  %.0f GB/s (alg 2x(in+out))" % (which, us, 2 * by / us / 1e3))
