@@ -1,0 +1,43 @@
+"""Synthetic stand-in for the reference's Kinetics multigrid dataset (kinetics_multigrid.py).
+
+The reference dataset decodes JPEG frame folders on NFS with PIL (out of scope);
+what matters for the hot path is the *shape protocol* of ``Kinetics.__getitem__``
+(kinetics_multigrid.py:214-259): the index carries (DataLoader task index, (sample, long-cycle
+state)), the clip comes back as float32 [3, T, H, W] with
+    (T, H=W) = f(long-cycle state, task index % 2 or % 3)
+together with ``(clip, target, long_cycle_state, stats)``.  ``SyntheticKinetics`` keeps exactly
+that protocol and fills the clip with N(0,1) noise (post-Normalize Kinetics frames are about
+zero-mean / unit-variance); ``device_batch`` produces a whole step's batch directly in HBM.
+"""
+import torch
+
+from cycle_batch_sampler import long_cycle_shapes, step_clip_shape
+
+
+class SyntheticKinetics(torch.utils.data.Dataset):
+    def __init__(self, n_samples=220000, n_classes=400, sample_duration=80, gamma_tau=5, crop_size=224, seed=0):
+        self.n_samples, self.n_classes = n_samples, n_classes
+        self.sample_duration, self.gamma_tau, self.crop_size = sample_duration, gamma_tau, crop_size
+        self.long_cycles = long_cycle_shapes(sample_duration, crop_size)
+        self.seed = seed
+
+    def __len__(self):
+        return self.n_samples
+
+    def __getitem__(self, index):
+        iteration = index[0]
+        idx, long_cycle_state = index[1]
+        frames, crop = self.long_cycles[long_cycle_state]
+        stats = (frames, crop // 2, int(crop / 2 ** 0.5), crop)
+        T, H = step_clip_shape(long_cycle_state, iteration, self.sample_duration, self.gamma_tau, self.crop_size)
+        g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
+        clip = torch.randn(3, T, H, H, generator=g)
+        target = int(torch.randint(0, self.n_classes, (1,), generator=g))
+        return clip, target, long_cycle_state, stats
+
+
+def device_batch(B, T, H, n_classes, device, generator=None):
+    """One step's synthetic batch generated in HBM: clips float32[B,3,T,H,H], labels int64[B,1]."""
+    x = torch.randn(B, 3, T, H, H, device=device, generator=generator)
+    y = torch.randint(0, n_classes, (B, 1), device=device, generator=generator)
+    return x, y

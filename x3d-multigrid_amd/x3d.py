@@ -207,6 +207,7 @@ class ResNet(nn.Module):
         self.in_planes = block_inplanes[0][1]
         self.index = 0
         self._pending_tracked = 0
+        self._bn_version = 0      # bumped when split_bn buffers are re-created (graph caches key on it)
 
         self.conv1_s = _Conv3dParams(n_input_channels, self.in_planes, (1, 3, 3), (1, 2, 2), (0, 1, 1))
         self.conv1_t = _Conv3dParams(self.in_planes, self.in_planes, (5, 1, 1), (1, 1, 1), (2, 0, 0),
@@ -250,6 +251,7 @@ class ResNet(nn.Module):
             if isinstance(m, SubBatchNorm3d):
                 m.num_splits = n
                 m.split_bn = _BNStats(m.num_features * n).to(m.weight.device)
+        self._bn_version += 1
         return n
 
     def aggregate_sub_bn_stats(self):

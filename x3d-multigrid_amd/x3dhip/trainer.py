@@ -50,20 +50,57 @@ class FlatParams:
         return [(cut, self.numel), (0, cut)]   # late layers + head first, early layers last
 
 
+class GradReducer:
+    """Data-parallel gradient exchange: sum the flat gradient over the ranks of ``pg`` with one
+    all-reduce per bucket (RCCL on GPUs -- backend "nccl" is RCCL on ROCm; gloo in the CPU
+    tests).  Buckets go out in reverse-autograd order on a side stream so that, when the
+    backward pass is split around them, the early buckets travel over xGMI while the remaining
+    backward kernels run.  The division by the world size happens in the fused SGD kernel."""
+
+    def __init__(self, flat_grad, buckets, world_size, process_group=None):
+        self.flat_grad, self.buckets, self.world, self.pg = flat_grad, buckets, world_size, process_group
+        self.stream = torch.cuda.Stream() if (world_size > 1 and flat_grad.is_cuda) else None
+
+    def reduce(self):
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        if self.stream is None:                       # CPU tensors (gloo)
+            for (a, b) in self.buckets:
+                dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for (a, b) in self.buckets:
+                dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+        cur.wait_stream(self.stream)
+
+
 class Trainer:
+    """Optimizer-like object (``param_groups``, ``state_dict`` in torch.optim.SGD's format) that
+    owns the whole training step."""
+
     def __init__(self, model, lr, momentum=0.9, weight_decay=5e-5, process_group=None, world_size=1,
                  use_graph=False):
         self.model = model
         self.fp = FlatParams(model)
-        self.lr = lr
-        self.momentum = momentum
-        self.weight_decay = weight_decay
+        self.param_groups = [dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay,
+                                  nesterov=False, params=list(range(len(self.fp.params))))]
         self.pg = process_group
         self.world = world_size
         self.first = True
         self.use_graph = use_graph
         self._graphs = {}
-        self._comm_stream = torch.cuda.Stream() if world_size > 1 else None
+        self.reducer = GradReducer(self.fp.grad, self.fp.head_first_buckets(model), world_size, process_group)
+
+    @property
+    def lr(self):
+        return self.param_groups[0]['lr']
+
+    @lr.setter
+    def lr(self, v):
+        self.param_groups[0]['lr'] = v
 
     # -- pieces ---------------------------------------------------------------------------
     def _fwd_bwd(self, x, y):
@@ -74,33 +111,34 @@ class Trainer:
         return loss.detach(), logits.detach()
 
     def _allreduce(self):
-        if self.world <= 1:
-            return
-        import torch.distributed as dist
-        cur = torch.cuda.current_stream()
-        self._comm_stream.wait_stream(cur)
-        with torch.cuda.stream(self._comm_stream):
-            for (a, b) in self.fp.head_first_buckets(self.model):
-                dist.all_reduce(self.fp.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg)
-        cur.wait_stream(self._comm_stream)
+        self.reducer.reduce()
 
     def _sgd(self):
-        ops.sgd_fused(self.fp.flat, self.fp.grad, self.fp.mom, self.lr, self.momentum, self.weight_decay,
+        g = self.param_groups[0]
+        ops.sgd_fused(self.fp.flat, self.fp.grad, self.fp.mom, g['lr'], g['momentum'], g['weight_decay'],
                       1.0 / self.world, first=self.first)
         self.first = False
 
     # -- public -----------------------------------------------------------------------------
     def step(self, x, y):
         """One optimizer step on clips x[B,3,T,H,W], labels y[B,1].  Returns (loss, logits)."""
-        if not self.use_graph:
-            loss, logits = self._fwd_bwd(x, y)
-            self._allreduce()
-            self._sgd()
-            return loss, logits
-        return self._graphed_step(x, y)
+        return self.train_step(x, y)
 
-    def _graphed_step(self, x, y):
-        key = (tuple(x.shape), self.model.bn1.num_splits, self.model.training)
+    def train_step(self, x, y, pre_step=None):
+        """forward + CE + backward (+ all-reduce) + SGD.  ``pre_step`` runs after backward and
+        before the parameter update (where the reference calls lr_warmup, train...:274)."""
+        if self.use_graph:
+            loss, logits = self._graphed_fwd_bwd(x, y)
+        else:
+            loss, logits = self._fwd_bwd(x, y)
+        self._allreduce()
+        if pre_step is not None:
+            pre_step()
+        self._sgd()                          # outside any graph: lr / first-step flag are host values
+        return loss, logits
+
+    def _graphed_fwd_bwd(self, x, y):
+        key = (tuple(x.shape), self.model._bn_version, self.model.training)
         ent = self._graphs.get(key)
         if ent is None:
             ent = self._capture(x, y)
@@ -109,16 +147,18 @@ class Trainer:
         ent["y"].copy_(y)
         ent["fb"].replay()
         self.model._pending_tracked += 1     # the replayed forward advanced every split-BN once
-        self._allreduce()
-        self._sgd()                          # outside the graph: lr / first-step flag are host values
         return ent["loss"], ent["logits"]
+
+    def invalidate_graphs(self):
+        """Captured graphs hold pointers to split_bn buffers: drop them when those are re-created
+        (update_bn_splits_long_cycle) or when parameters are re-homed."""
+        self._graphs.clear()
 
     def _capture(self, x, y):
         sx, sy = x.clone(), y.clone()
         # warm-up on a side stream (allocator + lazy init), restoring state that a real step mutates
-        keep = self.fp.flat.clone()
         bn_state = {k: v.clone() for k, v in self.model.state_dict().items() if "running_" in k}
-        pending = self.model._pending_tracked
+        pending = self.model._pending_tracked      # (state_dict() above flushed it: 0)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -129,9 +169,29 @@ class Trainer:
         with torch.cuda.graph(g):
             loss, logits = self._fwd_bwd(sx, sy)
         # undo the warm-up's side effects on BN running stats / counters
-        self.fp.flat.copy_(keep)
+        self.model._pending_tracked = pending
         sd = self.model.state_dict()
         for k, v in bn_state.items():
             sd[k].copy_(v)
-        self.model._pending_tracked = pending
         return dict(x=sx, y=sy, fb=g, loss=loss, logits=logits)
+
+    # -- torch.optim.SGD-compatible state (reference checkpoints, train...:185-187,286-291) ---
+    def state_dict(self):
+        state = {}
+        if not self.first:
+            for i, (o, k) in enumerate(self.fp.offsets):
+                state[i] = {'momentum_buffer': self.fp.mom[o:o + k].view(self.fp.params[i].shape).clone()}
+        return {'state': state, 'param_groups': [dict(self.param_groups[0])]}
+
+    def load_state_dict(self, sd):
+        g = sd['param_groups'][0]
+        for k in ('lr', 'momentum', 'weight_decay'):
+            if k in g:
+                self.param_groups[0][k] = g[k]
+        st = sd.get('state', {})
+        if st:
+            for i, (o, k) in enumerate(self.fp.offsets):
+                buf = st.get(i, st.get(str(i)))
+                if buf is not None and buf.get('momentum_buffer') is not None:
+                    self.fp.mom[o:o + k].copy_(buf['momentum_buffer'].reshape(-1).to(self.fp.mom.device))
+            self.first = False
