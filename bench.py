@@ -234,6 +234,9 @@ def main():
         # one instrumented eager step: HIP events around every launch, same tensors
         tr_e = tr
         tr_e.use_graph = False
+        for _ in range(2):          # eager warm-up: allocator + code objects outside the graph pool
+            tr_e.step(x, y)
+        torch.cuda.synchronize()
         with KernelTimer(ops) as kt:
             tr_e.step(x, y)
         agg = kt.summary()

@@ -108,7 +108,7 @@ int x3d_dw333_fwd(const float* x, const float* w, float* y,
  *   dY = cb0*g + cb1*a + cb2 (g,a at output resolution [N,C,T,Ho,Wo])
  *   hin = act(pre*x+pre)  (x raw [N,C,T,H,W])
  *   out = dw333^T(dY) * act'(pre*x+pre)           -> [N,C,T,H,W]
- *   dW[c,kt,kh,kw] partials: float[N][C][x3d_dw_bwd_tiles(H,W,s)][27]
+ *   dW[c,kt,kh,kw] partials: float[N][x3d_dw_bwd_tiles(H,W,s)][C][27] (group-sum over the first two dims)
  *   partial: float[N][C][x3d_dw_bwd_tiles(H,W,s)][2] {sum out, sum out*x}  */
 int x3d_dw_bwd_tiles(int H, int W, int strideHW);
 int x3d_dw333_bwd(const float* g, const float* a, const float* cb, const float* w,
@@ -129,7 +129,7 @@ int x3d_stem133_bwd_weight(const float* x, const float* dy, float* wpartial,
 int x3d_dw5t_tiles(int HW);
 int x3d_dw5t_fwd(const float* x, const float* w, float* y, int N, int C, int T, int HW,
                  float* partial, void* stream);
-/* dY = cb0*g+cb1*a+cb2; dx = dw5t^T(dY); dW partials float[N][C][tiles][5] (x = conv1_s output) */
+/* dY = cb0*g+cb1*a+cb2; dx = dw5t^T(dY); dW partials float[N][tiles][C][5] (x = conv1_s output) */
 int x3d_dw5t_bwd(const float* g, const float* a, const float* cb, const float* w, const float* x,
                  float* dx, float* wpartial, int N, int C, int T, int HW, void* stream);
 

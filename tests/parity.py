@@ -10,8 +10,11 @@ reference with the reference's own fp32-vs-fp64 discrepancy as the noise floor:
 
     err(candidate vs ref64)  <=  RTOL + K * err(ref32 vs ref64)
 
-with K = 2 for aggregate quantities (global norm, sketch, median over parameters) and K = 3 for
-per-parameter maxima.
+with K = 3.  The floor stored in a fixture is ONE draw of that rounding noise (the reference's
+fp32 run) and the candidate's error is another, independent draw of the same process, so their
+ratio scatters (observed 0.5 ... 2.5 across the fixtures and across kernel revisions that only
+changed summation order); K = 3 bounds it without hiding a real defect, which shows up as an
+error orders of magnitude above the floor (and in the kernel- and block-level tests).
 """
 import numpy as np
 
@@ -45,20 +48,20 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
     floor = abs(float(g["grad_global_norm"]) - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"])
     rep["global_norm_err"] = abs(gg - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"])
     rep["global_norm_floor"] = floor
-    assert rep["global_norm_err"] <= rtol + 2 * floor, rep
+    assert rep["global_norm_err"] <= rtol + 3 * floor, rep
     # per-parameter norms
     scale = n64 + 1e-6 * float(g["grad_global_norm64"])
     e_got = np.abs(got - n64) / scale
     e_ref = np.abs(n32 - n64) / scale
     rep["norm_err_median"], rep["norm_floor_median"] = float(np.median(e_got)), float(np.median(e_ref))
     rep["norm_err_max"], rep["norm_floor_max"] = float(e_got.max()), float(e_ref.max())
-    assert rep["norm_err_median"] <= rtol + 2 * rep["norm_floor_median"], rep
+    assert rep["norm_err_median"] <= rtol + 3 * rep["norm_floor_median"], rep
     assert rep["norm_err_max"] <= rtol + 3 * rep["norm_floor_max"], rep
     # whole-vector direction via the random-projection sketch
     sk = sketch_fn(grads)
     rep["sketch_err"] = rel(sk, g["grad_sketch64"])
     rep["sketch_floor"] = rel(g["grad_sketch"], g["grad_sketch64"])
-    assert rep["sketch_err"] <= rtol + 2 * rep["sketch_floor"], rep
+    assert rep["sketch_err"] <= rtol + 3 * rep["sketch_floor"], rep
     # the small gradients shipped in full
     worst = 0.0
     for k in g.files:

@@ -90,6 +90,107 @@ __global__ void bn_eval_coef_kernel(const float* __restrict__ rmean, const float
 }
 
 // ------------------------------------------------------------------------------------
+// Fused tile reduction + BN finalize: one workgroup per channel.  For every sample the 256
+// threads sum that (n, c) row's tile partials in fp64 (fixed order: thread-strided, then a
+// fixed tree), thread 0 adds the row sum to its split; then one thread per split finishes.
+// ------------------------------------------------------------------------------------
+constexpr int BN_MAXS = 256;
+constexpr int BN_MAXN = 1024;
+
+// Per-sample row sums for one channel: wave w takes samples w, w+4, ...; lanes stride the tiles;
+// fp64 wave reduction by shuffles (no barrier per sample, loads of consecutive samples overlap).
+__device__ __forceinline__ void channel_row_sums(const float* __restrict__ partial, int N, int C, int c, int tiles,
+                                                 double* rows /* [N][2] in LDS */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = wave; n < N; n += 4) {
+        const float* p = partial + ((size_t)n * C + c) * tiles * 2;
+        double a = 0.0, b = 0.0;
+        for (int t = lane; t < tiles; t += 64) {
+            const float2 v = *reinterpret_cast<const float2*>(p + 2 * t);
+            a += (double)v.x;
+            b += (double)v.y;
+        }
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (lane == 0) { rows[2 * n] = a; rows[2 * n + 1] = b; }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const float* __restrict__ partial, int N, int C, int tiles,
+                                                           int S, int count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, float momentum, float eps,
+                                                           float* __restrict__ coef, float* __restrict__ save,
+                                                           float* __restrict__ nsum) {
+    __shared__ double rows[2 * BN_MAXN];
+    __shared__ float csc[BN_MAXS], csh[BN_MAXS];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    channel_row_sums(partial, N, C, c, tiles, rows);
+    const double cnt = (double)count * (double)(N / S);
+    for (int j = tid; j < S; j += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int n = j; n < N; n += S) { s1 += rows[2 * n]; s2 += rows[2 * n + 1]; }
+        const double mean = s1 / cnt;
+        double var = s2 / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        save[(size_t)j * C + c] = (float)mean;
+        save[(size_t)(S + j) * C + c] = (float)invstd;
+        if (rmean != nullptr) {
+            const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            rmean[(size_t)j * C + c] = (float)((1.0 - momentum) * rmean[(size_t)j * C + c] + momentum * mean);
+            rvar[(size_t)j * C + c] = (float)((1.0 - momentum) * rvar[(size_t)j * C + c] + momentum * unb);
+        }
+        csc[j] = (float)((double)gamma[c] * invstd);
+        csh[j] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += 256) {
+        coef[((size_t)n * C + c) * 2] = csc[n % S];
+        coef[((size_t)n * C + c) * 2 + 1] = csh[n % S];
+        if (nsum != nullptr) nsum[(size_t)n * C + c] = (float)rows[2 * n];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restrict__ partial, int N, int C, int tiles,
+                                                           int S, int count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ save, float* __restrict__ cb,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int accumulate) {
+    __shared__ double rows[2 * BN_MAXN];
+    __shared__ float cA[BN_MAXS], cB[BN_MAXS], cC[BN_MAXS];
+    __shared__ double dgs[BN_MAXS], dbs[BN_MAXS];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    channel_row_sums(partial, N, C, c, tiles, rows);
+    const double M = (double)count * (double)(N / S);
+    const double g = gamma[c];
+    for (int j = tid; j < S; j += 256) {
+        double sg = 0.0, sga = 0.0;
+        for (int n = j; n < N; n += S) { sg += rows[2 * n]; sga += rows[2 * n + 1]; }
+        const double mean = save[(size_t)j * C + c], invstd = save[(size_t)(S + j) * C + c];
+        const double sgx = (sga - mean * sg) * invstd;
+        const double k = g * invstd;
+        cA[j] = (float)k;
+        cB[j] = (float)(-k * invstd * sgx / M);
+        cC[j] = (float)(-k * sg / M + k * invstd * mean * sgx / M);
+        dgs[j] = sgx;
+        dbs[j] = sg;
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += 256) {
+        cb[((size_t)n * C + c) * 3] = cA[n % S];
+        cb[((size_t)n * C + c) * 3 + 1] = cB[n % S];
+        cb[((size_t)n * C + c) * 3 + 2] = cC[n % S];
+    }
+    if (tid == 0) {
+        double dg = 0.0, db = 0.0;
+        for (int j = 0; j < S; ++j) { dg += dgs[j]; db += dbs[j]; }
+        if (accumulate) { dgamma[c] += (float)dg; dbeta[c] += (float)db; }
+        else { dgamma[c] = (float)dg; dbeta[c] = (float)db; }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // SE forward: one workgroup per sample
 // ------------------------------------------------------------------------------------
 constexpr int SE_MAXC = 1024, SE_MAXW = 64;
@@ -405,10 +506,15 @@ extern "C" int x3d_bn_fwd_finalize(const float* partial, int N, int C, int tiles
         return X3D_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;
-    double* dsum = (double*)scratch;
-    hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dsum, N, C, S, count, gamma,
-                       beta, running_mean, running_var, momentum, eps, coef, save, nsum);
+    if (S <= BN_MAXS && N <= BN_MAXN) {
+        hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3(C), dim3(256), 0, s, partial, N, C, tiles, S, count, gamma, beta,
+                           running_mean, running_var, momentum, eps, coef, save, nsum);
+    } else {
+        double* dsum = (double*)scratch;
+        hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
+        hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dsum, N, C, S, count, gamma,
+                           beta, running_mean, running_var, momentum, eps, coef, save, nsum);
+    }
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
@@ -439,11 +545,16 @@ extern "C" int x3d_bn_bwd_finalize(const float* partial, int N, int C, int tiles
     X3D_CHECK_ARG(partial && gamma && save && cb && dgamma && dbeta && scratch);
     X3D_CHECK_ARG(N > 0 && C > 0 && tiles > 0 && S > 0 && count > 0 && N % S == 0);
     hipStream_t s = (hipStream_t)stream;
-    double* dsum = (double*)scratch;
-    hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dsum, N, C, S, count, gamma, save,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cb, dgamma, dbeta,
-                       accumulate);
+    if (S <= BN_MAXS && N <= BN_MAXN) {
+        hipLaunchKernelGGL(bn_bwd_fused_kernel, dim3(C), dim3(256), 0, s, partial, N, C, tiles, S, count, gamma, save,
+                           cb, dgamma, dbeta, accumulate);
+    } else {
+        double* dsum = (double*)scratch;
+        hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dsum, N, C, S, count, gamma,
+                           save, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cb, dgamma,
+                           dbeta, accumulate);
+    }
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             float s = 0.f;
             for (int i = 0; i < g.ipc; ++i) s += rb[k * 256 + ch * g.ipc + i];
             const size_t row_id = ((size_t)n * g.C + c0 + ch) * g.tiles + tile;
-            if (k < 27) A.wpartial[row_id * 27 + k] = s;
+            if (k < 27) A.wpartial[(((size_t)n * g.tiles + tile) * g.C + c0 + ch) * 27 + k] = s;   // [N][tiles][C][27]
             else if (A.partial != nullptr) A.partial[row_id * 2 + (k - 27)] = s;
         }
     }

@@ -65,24 +65,12 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[NT]) {
     else p[0] = v[0];
 }
 
-constexpr int PW_MAXK = 640;   // per-sample input-coefficient table in LDS (XL: 630 channels)
-
 template <int MT, int NT, int IN, int EPI>
 __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
-    // K is consumed in chunks of KC channels staged in LDS (weights) / registers (activations).
-    //   NT = 4 (64 voxels per wave, large-P layers): KC = 32, activations fetched in two groups of
-    //          4 k-steps, one group ahead (also across the chunk boundary);
-    //   NT = 1 (16 voxels per wave, small-P / large-C layers): KC = 128 and the whole chunk's
-    //          activations are issued in one burst together with the weight chunk, so a wave
-    //          exposes one load latency per 32 k-steps instead of one per 4.
-    constexpr int GS = (NT == 1) ? 32 : 4;     // k-steps per activation group
-    constexpr int G = (NT == 1) ? 1 : 2;       // groups per chunk
-    constexpr int KC = 4 * GS * G;
-    constexpr int KPAD = KC + 2;               // conflict-free A-fragment reads
-    constexpr int NC = (IN == IN_BNBWD) ? 3 : 2;
-    __shared__ float Wl[MT * 16 * KPAD];
+    constexpr int PW_KC = 32;     // channels per LDS weight chunk
+    constexpr int PW_KPAD = 34;   // LDS row stride of the weight chunk (conflict-free fragment reads)
+    __shared__ float Wl[MT * 16 * PW_KPAD];
     __shared__ float red[4 * MT * 16 * 2];
-    __shared__ float Cl[(IN == IN_RAW) ? 4 : 3 * PW_MAXK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
@@ -107,48 +95,69 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
         off = (t * A.H + 2 * ho) * A.W + 2 * wo;
     }
 
-    if (IN != IN_RAW) {                          // this sample's input coefficients -> LDS
-        for (int i = tid; i < K * NC; i += 256) Cl[i] = A.cin[(size_t)n * K * NC + i];
-    }
-
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = (K + KC - 1) / KC;
-    const int ngroups = ((K + 3) / 4 + GS - 1) / GS;
-    const float* xrow = A.x + (size_t)n * K * (size_t)A.Pin + off;
-    const float* arow = (IN == IN_BNBWD) ? A.a + (size_t)n * K * (size_t)P + off : nullptr;
+    const int nsteps = (K + 3) / 4;        // k-steps of 4 channels
+    const int nchunks = (K + PW_KC - 1) / PW_KC;
 
-    float rx[GS][NT], ra[(IN == IN_BNBWD) ? GS : 1][NT];
+    // register staging of one half chunk (4 k-steps = 16 channels)
+    float rx[4][NT], ra[4][NT];
+    float c0[4], c1[4], c2[4];
 
-    auto load_group = [&](int gi) {              // gi = global group index
+    auto load_half = [&](int hc) {
 #pragma unroll
-        for (int ks = 0; ks < GS; ++ks) {
-            const int k = (gi * GS + ks) * 4 + q;
-            const bool ok = (k < K) && pv;
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = hc * 16 + ks * 4 + q;
+            const bool kv = k < K;
+            const int kc = kv ? k : 0;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) rx[ks][j] = 0.f;
-            if (ok) vload<NT>(xrow + (size_t)k * (size_t)A.Pin, rx[ks]);
+            for (int j = 0; j < NT; ++j) { rx[ks][j] = 0.f; ra[ks][j] = 0.f; }
+            if (kv && pv) vload<NT>(A.x + ((size_t)n * K + kc) * (size_t)A.Pin + off, rx[ks]);
             if (IN == IN_BNBWD) {
+                if (kv && pv) vload<NT>(A.a + ((size_t)n * K + kc) * (size_t)P + off, ra[ks]);
+                const float* pc = A.cin + ((size_t)n * K + kc) * 3;
+                c0[ks] = kv ? pc[0] : 0.f;
+                c1[ks] = kv ? pc[1] : 0.f;
+                c2[ks] = kv ? pc[2] : 0.f;
+            } else if (IN == IN_AFFACT) {
+                const float* pc = A.cin + ((size_t)n * K + kc) * 2;
+                c0[ks] = kv ? pc[0] : 0.f;
+                c1[ks] = kv ? pc[1] : 0.f;
+                c2[ks] = kv ? 1.f : 0.f;
+            }
+        }
+    };
+
+    float xb[4][NT];
+    auto combine_half = [&]() {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) ra[ks][j] = 0.f;
-                if (ok) vload<NT>(arow + (size_t)k * (size_t)P, ra[ks]);
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float v = rx[ks][j];
+                if (IN == IN_BNBWD) {
+                    v = pv ? fmaf(c0[ks], v, fmaf(c1[ks], ra[ks][j], c2[ks])) : 0.f;
+                } else if (IN == IN_AFFACT) {
+                    v = (c2[ks] != 0.f && pv) ? act_fwd(fmaf(c0[ks], v, c1[ks]), A.in_act) : 0.f;
+                }
+                xb[ks][j] = v;
             }
         }
     };
 
     auto stage_w = [&](int c) {
-        const int k0 = c * KC;
-        const int total = mt_run * 16 * KC;
+        const int k0 = c * PW_KC;
+        const int total = mt_run * 16 * PW_KC;
         if (A.w_ldk == 1) {   // forward layout: k contiguous in memory
             for (int idx = tid; idx < total; idx += 256) {
-                const int m = idx / KC, kk = idx - m * KC;
+                const int m = idx >> 5, kk = idx & 31;
                 float v = 0.f;
                 if (m < bm && k0 + kk < K) v = A.w[(size_t)(m0 + m) * A.w_ldm + (k0 + kk)];
-                Wl[m * KPAD + kk] = v;
+                Wl[m * PW_KPAD + kk] = v;
             }
         } else {              // transposed use (backward-data): m contiguous in memory
             const int rows = mt_run * 16;
@@ -156,93 +165,41 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
                 const int kk = idx / rows, m = idx - kk * rows;
                 float v = 0.f;
                 if (m < bm && k0 + kk < K) v = A.w[(size_t)(k0 + kk) * A.w_ldk + (m0 + m)];
-                Wl[m * KPAD + kk] = v;
+                Wl[m * PW_KPAD + kk] = v;
             }
         }
     };
 
-    // combine (prologue) + MFMA for one group; kl0 = first channel of the group inside the chunk
-    auto compute_group = [&](int gi, int kl0) {
+    auto compute_half = [&](int half) {
 #pragma unroll
-        for (int ks = 0; ks < GS; ++ks) {
-            const int k = (gi * GS + ks) * 4 + q;
-            const bool ok = (k < K) && pv;
-            float xb[NT];
-            if (IN == IN_BNBWD) {
-                const float k0c = ok ? Cl[k * 3] : 0.f, k1c = ok ? Cl[k * 3 + 1] : 0.f, k2c = ok ? Cl[k * 3 + 2] : 0.f;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) xb[j] = fmaf(k0c, rx[ks][j], fmaf(k1c, ra[ks][j], k2c));
-            } else if (IN == IN_AFFACT) {
-                const float sc = ok ? Cl[k * 2] : 0.f, sh = ok ? Cl[k * 2 + 1] : 0.f;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) xb[j] = ok ? act_fwd(fmaf(sc, rx[ks][j], sh), A.in_act) : 0.f;
-            } else {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) xb[j] = rx[ks][j];
-            }
-            const int kk = kl0 + ks * 4 + q;
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = half * 16 + ks * 4 + q;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if (mt < mt_run) {
-                    const float av = Wl[(mt * 16 + r) * KPAD + kk];
+                    const float av = Wl[(mt * 16 + r) * PW_KPAD + kk];
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[j], acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[ks][j], acc[mt][j], 0, 0, 0);
                 }
             }
         }
     };
 
-    if (NT == 4) {
-        // two groups per chunk; the next group's loads are always issued before the current
-        // group's MFMAs (also across the chunk boundary), so one group is always in flight
-        float nx[GS][NT], na[(IN == IN_BNBWD) ? GS : 1][NT];
-        auto prefetch = [&](int gi) {
-#pragma unroll
-            for (int ks = 0; ks < GS; ++ks) {
-                const int k = (gi * GS + ks) * 4 + q;
-                const bool ok = (k < K) && pv;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) nx[ks][j] = 0.f;
-                if (ok) vload<NT>(xrow + (size_t)k * (size_t)A.Pin, nx[ks]);
-                if (IN == IN_BNBWD) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) na[ks][j] = 0.f;
-                    if (ok) vload<NT>(arow + (size_t)k * (size_t)P, na[ks]);
-                }
-            }
-        };
-        auto take = [&]() {
-#pragma unroll
-            for (int ks = 0; ks < GS; ++ks)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    rx[ks][j] = nx[ks][j];
-                    if (IN == IN_BNBWD) ra[ks][j] = na[ks][j];
-                }
-        };
-        prefetch(0);
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();
-            stage_w(c);
-            __syncthreads();
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int gi = c * G + g;
-                if (gi < ngroups) {
-                    take();
-                    if (gi + 1 < ngroups) prefetch(gi + 1);
-                    compute_group(gi, g * GS * 4);
-                }
-            }
-        }
-    } else {
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();
-            load_group(c);          // whole chunk's activations in flight ...
-            stage_w(c);             // ... together with the weight chunk
-            __syncthreads();
-            compute_group(c, 0);
+    const int nhalf = (nsteps + 3) / 4;
+    load_half(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        stage_w(c);
+        __syncthreads();
+        const int h0 = 2 * c;
+        combine_half();
+        if (h0 + 1 < nhalf) load_half(h0 + 1);
+        compute_half(0);
+        if (h0 + 1 < nhalf) {
+            combine_half();
+            if (h0 + 2 < nhalf) load_half(h0 + 2);
+            compute_half(1);
         }
     }
 

@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void dw5t_bwd_kernel(const float* __restrict__
     block_sum_256<5>(dw, red, o5);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) wpartial[((size_t)row * tiles + blockIdx.x) * 5 + k] = o5[k];
+        for (int k = 0; k < 5; ++k)   // layout [N][tiles][C][5]: a plain group sum over (n, tile) finishes it
+            wpartial[((((size_t)(row / C)) * tiles + blockIdx.x) * C + c) * 5 + k] = o5[k];
     }
 }
 

@@ -152,17 +152,36 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx):
     return out, None
 
 
+class _GradSink:
+    """Where parameter gradients go.  Default: fresh tensors handed back to autograd (which
+    accumulates them into .grad).  Direct mode (set by x3dhip.trainer.Trainer, which owns a
+    zeroed flat gradient buffer): kernels write straight into the existing .grad storage and
+    autograd gets None -- 300+ tiny accumulate kernels per step disappear."""
+
+    def __init__(self, direct):
+        self.direct = direct
+        self.written = {}
+
+    def out(self, p):
+        if self.direct and p.grad is not None:
+            return p.grad.view(-1)
+        return None
+
+    def put(self, p, t):
+        self.written[p] = t
+
+
 def trunk_backward(model, ctx, dpooled, grads):
-    """dpooled: [N, C5] gradient w.r.t. trunk_forward's result.  Fills grads[param] = tensor
-    for every trunk parameter (keyed by the Parameter object)."""
+    """dpooled: [N, C5] gradient w.r.t. trunk_forward's result.  Fills grads.written[param] for
+    every trunk parameter (grads: _GradSink)."""
     hd = ctx.head
     S = hd["S"]
     a5 = hd["a5"]
     P5 = a5[0, 0].numel()
     g5, pp = ops.bn_relu_pool_bwd(a5, hd["c5"], dpooled.contiguous())
-    cb5, dg, db = ops.bn_bwd_finalize(pp, S, P5, model.bn5.weight.data, hd["save5"])
-    grads[model.bn5.weight], grads[model.bn5.bias] = dg, db
-    grads[model.conv5.weight] = ops.pw_bwd_weight(g5, a5, cb5, hd["x4"], model.conv5.weight.shape)
+    _bn_bwd(grads, pp, S, P5, model.bn5, hd["save5"], out_cb=True)
+    cb5 = grads.last_cb
+    _wgrad(grads, model.conv5.weight, g5, a5, cb5, hd["x4"])
     dcur, _ = ops.pw_bwd_data(g5, a5, cb5, _w2d(model.conv5.weight))
     del g5
 
@@ -173,11 +192,25 @@ def trunk_backward(model, ctx, dpooled, grads):
     st = ctx.stem
     a_t = st["a_t"]
     P = a_t[0, 0].numel()
-    cb0, dg, db = ops.bn_bwd_finalize(pstem, S, P, model.bn1.weight.data, st["save0"])
-    grads[model.bn1.weight], grads[model.bn1.bias] = dg, db
-    dx_s, dwt = ops.dw5t_bwd(dcur, a_t, cb0, model.conv1_t.weight.data, st["a_s"])
-    grads[model.conv1_t.weight] = dwt
-    grads[model.conv1_s.weight] = ops.stem133_bwd_weight(st["x"], dx_s, model.conv1_s.weight.shape)
+    _bn_bwd(grads, pstem, S, P, model.bn1, st["save0"])
+    cb0 = grads.last_cb
+    w_t, w_s = model.conv1_t.weight, model.conv1_s.weight
+    dx_s, dwt = ops.dw5t_bwd(dcur, a_t, cb0, w_t.data, st["a_s"], dw_out=grads.out(w_t))
+    grads.put(w_t, dwt)
+    grads.put(w_s, ops.stem133_bwd_weight(st["x"], dx_s, w_s.shape, out=grads.out(w_s)))
+
+
+def _bn_bwd(grads, partial, S, count, bn, save, out_cb=True):
+    cb, dg, db = ops.bn_bwd_finalize(partial, S, count, bn.weight.data, save, dgamma=grads.out(bn.weight),
+                                     dbeta=grads.out(bn.bias))
+    grads.put(bn.weight, dg)
+    grads.put(bn.bias, db)
+    grads.last_cb = cb
+    return cb
+
+
+def _wgrad(grads, w, g, a, cb, x, **kw):
+    grads.put(w, ops.pw_bwd_weight(g, a, cb, x, w.shape, out=grads.out(w), **kw))
 
 
 def _block_backward(rec, dout, grads):
@@ -188,41 +221,42 @@ def _block_backward(rec, dout, grads):
     P1, P2 = a1[0, 0].numel(), a2[0, 0].numel()
 
     g3, p3, pd = ops.bn_add_relu_bwd(dout, rec["out"], a3, ad)
-    cb3, dg, db = ops.bn_bwd_finalize(p3, S, P2, blk.bn3.weight.data, rec["s3"])
-    grads[blk.bn3.weight], grads[blk.bn3.bias] = dg, db
+    cb3 = _bn_bwd(grads, p3, S, P2, blk.bn3, rec["s3"])
 
     # conv3: weight gradient, then data gradient fused with the swish backward
-    grads[blk.conv3.weight] = ops.pw_bwd_weight(g3, a3, cb3, a2, blk.conv3.weight.shape,
-                                                pre=rec["c2e"], pre_act=ACT_SWISH)
+    _wgrad(grads, blk.conv3.weight, g3, a3, cb3, a2, pre=rec["c2e"], pre_act=ACT_SWISH)
     ds, ps = ops.pw_bwd_data(g3, a3, cb3, _w2d(blk.conv3.weight), x=a2, pre=rec["c2e"], pre_act=ACT_SWISH)
     if blk.has_se:
         se = rec["se"]
+        outs = None
+        if grads.direct and blk.bn2.weight.grad is not None:
+            outs = dict(dgamma=blk.bn2.weight.grad, dbeta=blk.bn2.bias.grad, dw1=blk.fc1.weight.grad.view(-1),
+                        db1=blk.fc1.bias.grad, dw2=blk.fc2.weight.grad.view(-1), db2=blk.fc2.bias.grad)
         cb2, o = ops.se_bn_bwd_finalize(ps, S, P2, blk.bn2.weight.data, blk.bn2.bias.data, rec["s2"], se["nsum"],
-                                        _w2d(blk.fc1.weight), _w2d(blk.fc2.weight), se["se"], se["z"], se["pool"])
-        grads[blk.bn2.weight], grads[blk.bn2.bias] = o["dgamma"], o["dbeta"]
-        grads[blk.fc1.weight], grads[blk.fc1.bias] = o["dw1"].view(blk.fc1.weight.shape), o["db1"]
-        grads[blk.fc2.weight], grads[blk.fc2.bias] = o["dw2"].view(blk.fc2.weight.shape), o["db2"]
+                                        _w2d(blk.fc1.weight), _w2d(blk.fc2.weight), se["se"], se["z"], se["pool"],
+                                        outs=outs)
+        grads.put(blk.bn2.weight, o["dgamma"])
+        grads.put(blk.bn2.bias, o["dbeta"])
+        grads.put(blk.fc1.weight, o["dw1"])
+        grads.put(blk.fc1.bias, o["db1"])
+        grads.put(blk.fc2.weight, o["dw2"])
+        grads.put(blk.fc2.bias, o["db2"])
     else:
-        cb2, dg, db = ops.bn_bwd_finalize(ps, S, P2, blk.bn2.weight.data, rec["s2"])
-        grads[blk.bn2.weight], grads[blk.bn2.bias] = dg, db
+        cb2 = _bn_bwd(grads, ps, S, P2, blk.bn2, rec["s2"])
 
     # conv2 (channelwise): fused data + weight backward, relu backward of bn1 in its epilogue
     g1, dw2, p1 = ops.dw333_bwd(ds, a2, cb2, blk.conv2.weight.data, a1, stride=blk.stride, pre=rec["c1"],
-                                pre_act=ACT_RELU)
+                                pre_act=ACT_RELU, dw_out=grads.out(blk.conv2.weight))
     del ds
-    grads[blk.conv2.weight] = dw2
-    cb1, dg, db = ops.bn_bwd_finalize(p1, S, P1, blk.bn1.weight.data, rec["s1"])
-    grads[blk.bn1.weight], grads[blk.bn1.bias] = dg, db
+    grads.put(blk.conv2.weight, dw2)
+    cb1 = _bn_bwd(grads, p1, S, P1, blk.bn1, rec["s1"])
 
     # conv1 (+ downsample branch)
-    grads[blk.conv1.weight] = ops.pw_bwd_weight(g1, a1, cb1, x_raw, blk.conv1.weight.shape, pre=x_coef,
-                                                pre_act=pre_act)
+    _wgrad(grads, blk.conv1.weight, g1, a1, cb1, x_raw, pre=x_coef, pre_act=pre_act)
     if blk.downsample is not None:
         dsc, dsb = blk.downsample[0], blk.downsample[1]
-        cbd, dg, db = ops.bn_bwd_finalize(pd, S, P2, dsb.weight.data, rec["sd"])
-        grads[dsb.weight], grads[dsb.bias] = dg, db
-        grads[dsc.weight] = ops.pw_bwd_weight(g3, ad, cbd, x_raw, dsc.weight.shape, stride=blk.stride, pre=x_coef,
-                                              pre_act=pre_act)
+        cbd = _bn_bwd(grads, pd, S, P2, dsb, rec["sd"])
+        _wgrad(grads, dsc.weight, g3, ad, cbd, x_raw, stride=blk.stride, pre=x_coef, pre_act=pre_act)
         addend, _ = ops.pw_bwd_data(g3, ad, cbd, _w2d(dsc.weight))
         astride = blk.stride
     else:
@@ -257,9 +291,14 @@ class TrunkFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpooled):
-        grads = {}
-        trunk_backward(ctx.model, ctx.tctx, dpooled, grads)
+        sink = _GradSink(getattr(ctx.model, "_direct_grads", False))
+        trunk_backward(ctx.model, ctx.tctx, dpooled, sink)
         ctx.tctx = None
-        plist = trunk_parameters(ctx.model)
-        out = [grads[p].view(p.shape) for p in plist]
+        out = []
+        for p in trunk_parameters(ctx.model):
+            t = sink.written[p]
+            if sink.direct and p.grad is not None and t.data_ptr() == p.grad.data_ptr():
+                out.append(None)              # already written in place
+            else:
+                out.append(t.view(p.shape))
         return (None, None) + tuple(out)

@@ -119,15 +119,13 @@ def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wp
     tiles = L.x3d_dw_bwd_tiles(H, W, stride)
     o = out if out is not None else _f(x.shape, x)
     if wpartial is None:
-        wpartial = _f((N, C, tiles, 27), x)
+        wpartial = _f((N, tiles, C, 27), x)
     if partial is None:
         partial = _f((N, C, tiles, 2), x)
     check(L.x3d_dw333_bwd(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(x), ptr(pre), pre_act, ptr(o), ptr(wpartial),
                           ptr(partial), N, C, T, H, W, stride, _lib.stream()))
-    # dW[c][27] = sum over n and tiles.  Reuse the tile reducer: view as [N][C*tiles*27] is not
-    # a plain group sum, so reduce with a strided view: [N*tiles groups] x [C*27]
-    wp = wpartial.permute(0, 2, 1, 3).contiguous().view(N * tiles, C * 27)
-    dw = reduce_partials(wp, C * 27, out=dw_out)
+    # dW[c][27] = sum over (n, tile) groups of the [N][tiles][C][27] partials
+    dw = reduce_partials(wpartial.view(N * tiles, C * 27), C * 27, out=dw_out)
     return o, dw.view(w.shape), partial
 
 
@@ -169,10 +167,9 @@ def dw5t_bwd(g, a, cb, w, x, out=None, dw_out=None):
     N, C, T, H, W = x.shape
     tiles = L.x3d_dw5t_tiles(H * W)
     dx = out if out is not None else _f(x.shape, x)
-    wp = _f((N, C, tiles, 5), x)
+    wp = _f((N, tiles, C, 5), x)
     check(L.x3d_dw5t_bwd(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(x), ptr(dx), ptr(wp), N, C, T, H * W, _lib.stream()))
-    wp2 = wp.permute(0, 2, 1, 3).contiguous().view(N * tiles, C * 5)
-    return dx, reduce_partials(wp2, C * 5, out=dw_out).view(w.shape)
+    return dx, reduce_partials(wp.view(N * tiles, C * 5), C * 5, out=dw_out).view(w.shape)
 
 
 # ----------------------------------------------------------------------------- BN / SE

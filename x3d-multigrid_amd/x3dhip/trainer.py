@@ -92,6 +92,7 @@ class Trainer:
         self.first = True
         self.use_graph = use_graph
         self._graphs = {}
+        model._direct_grads = True      # engine writes parameter gradients straight into fp.grad
         self.reducer = GradReducer(self.fp.grad, self.fp.head_first_buckets(model), world_size, process_group)
 
     @property
