@@ -62,82 +62,99 @@ struct DwFwdArgs {
     DwGeom g;
 };
 
-// Fetch one plane (time index t) of the RAW input into registers (loads stay in flight).
-// chunk idx -> (cc, ih, w4); NCH chunks per thread.
+// Per-thread descriptor of one staged float4 chunk; everything that does not depend on t is
+// computed once before the T march (no division in the loop).
+struct Chunk {
+    int goff;      // element offset of the chunk inside one (n) volume, t = 0; < 0: nothing to load
+    int loff;      // float offset inside an LDS slot; < 0: chunk not owned by this thread
+    int nval;      // valid elements of the float4 (0..4)
+    float sc, sh;  // producer BN scale / shift of the chunk's channel
+};
+
 template <int NCH>
-__device__ __forceinline__ void fwd_fetch(const DwFwdArgs& A, int n, int c0, int h_in0, int t, float4 (&reg)[NCH]) {
-    const DwGeom& g = A.g;
-    const int w4n = g.WP / 4 - 2;                 // data chunks per row (cols 4 .. WP-5)
+__device__ __forceinline__ void make_chunks(const DwGeom& g, int n, int c0, int row0, int SH, int SW,
+                                            const float* pre, Chunk (&ch)[NCH]) {
+    // staged tensor: rows row0 .. row0+IH-1 of a [C][T][SH][SW] volume
+    const int w4n = g.WP / 4 - 2;
     const int total = g.cpb * g.IH * w4n;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int idx = i * 256 + threadIdx.x;
+        Chunk c;
+        c.goff = -1; c.loff = -1; c.nval = 0; c.sc = 1.f; c.sh = 0.f;
+        if (idx < total) {
+            const int rowi = idx / w4n, w4 = idx - rowi * w4n;     // rowi = cc*IH + ih
+            const int cc = rowi / g.IH, ih = rowi - cc * g.IH;
+            const int cg = c0 + cc, hi = row0 + ih, w = w4 * 4;
+            c.loff = rowi * g.WP + DW_PADL + w;
+            if (cg < g.C && hi >= 0 && hi < SH && w < SW) {
+                c.goff = ((cg * g.T) * SH + hi) * SW + w;
+                c.nval = min(4, SW - w);
+                if (pre != nullptr) { c.sc = pre[((size_t)n * g.C + cg) * 2]; c.sh = pre[((size_t)n * g.C + cg) * 2 + 1]; }
+            }
+        }
+        ch[i] = c;
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chunk (&ch)[NCH], int toff, bool tvalid,
+                                       bool vec, float4 (&reg)[NCH]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < total && t >= 0 && t < g.T) {
-            const int cc = idx / (g.IH * w4n);
-            const int rem = idx - cc * (g.IH * w4n);
-            const int ih = rem / w4n, w4 = rem - ih * w4n;
-            const int c = c0 + cc, hi = h_in0 + ih, w = w4 * 4;
-            if (c < g.C && hi >= 0 && hi < g.H && w < g.W) {
-                const float* p = A.x + ((((size_t)n * g.C + c) * g.T + t) * g.H + hi) * (size_t)g.W + w;
-                if ((g.W & 3) == 0) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    v.x = p[0];
-                    if (w + 1 < g.W) v.y = p[1];
-                    if (w + 2 < g.W) v.z = p[2];
-                    if (w + 3 < g.W) v.w = p[3];
-                }
+        if (tvalid && ch[i].goff >= 0) {
+            const float* p = base + ch[i].goff + toff;
+            if (vec) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                v.x = p[0];
+                if (ch[i].nval > 1) v.y = p[1];
+                if (ch[i].nval > 2) v.z = p[2];
+                if (ch[i].nval > 3) v.w = p[3];
             }
         }
         reg[i] = v;
     }
 }
 
-// Apply the producer's BN + activation and store into the slot; everything outside the tensor
-// (padding rows, t out of range, w >= W) is stored as exact zero.
+// activation applied while storing; everything outside the tensor is exact zero
 template <int NCH>
-__device__ __forceinline__ void fwd_store(const DwFwdArgs& A, int n, int c0, int h_in0, int t, float* slot,
+__device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], bool tvalid, int act,
                                           const float4 (&reg)[NCH]) {
-    const DwGeom& g = A.g;
-    const int w4n = g.WP / 4 - 2;
-    const int total = g.cpb * g.IH * w4n;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int idx = i * 256 + threadIdx.x;
-        if (idx < total) {
-            const int rowi = idx / w4n, w4 = idx - rowi * w4n;     // rowi = cc*IH + ih
-            const int cc = rowi / g.IH, ih = rowi - cc * g.IH;
-            const int c = c0 + cc, hi = h_in0 + ih, w = w4 * 4;
+        if (ch[i].loff >= 0) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < g.T && c < g.C && hi >= 0 && hi < g.H && w < g.W) {
-                float sc = 1.f, sh = 0.f;
-                if (A.pre != nullptr) { sc = A.pre[((size_t)n * g.C + c) * 2]; sh = A.pre[((size_t)n * g.C + c) * 2 + 1]; }
-                v.x = act_fwd(fmaf(sc, reg[i].x, sh), A.pre_act);
-                if (w + 1 < g.W) v.y = act_fwd(fmaf(sc, reg[i].y, sh), A.pre_act);
-                if (w + 2 < g.W) v.z = act_fwd(fmaf(sc, reg[i].z, sh), A.pre_act);
-                if (w + 3 < g.W) v.w = act_fwd(fmaf(sc, reg[i].w, sh), A.pre_act);
+            if (tvalid && ch[i].goff >= 0) {
+                const float sc = ch[i].sc, sh = ch[i].sh;
+                v.x = act_fwd(fmaf(sc, reg[i].x, sh), act);
+                if (ch[i].nval > 1) v.y = act_fwd(fmaf(sc, reg[i].y, sh), act);
+                if (ch[i].nval > 2) v.z = act_fwd(fmaf(sc, reg[i].z, sh), act);
+                if (ch[i].nval > 3) v.w = act_fwd(fmaf(sc, reg[i].w, sh), act);
             }
-            *reinterpret_cast<float4*>(slot + (size_t)rowi * g.WP + DW_PADL + w4 * 4) = v;
+            *reinterpret_cast<float4*>(slot + ch[i].loff) = v;
         }
     }
 }
 
+// Forward.  LDS holds two planes (double buffer); every thread keeps the values of the three
+// planes its stencil touches in registers (sliding window along T), so each staged value is
+// read from LDS once per consumer instead of three times.
 template <int NCH, int STRIDE>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NV = (STRIDE == 1) ? 18 : 27;          // window values per plane
     const DwGeom& g = A.g;
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, c0 = blockIdx.y * g.cpb, n = blockIdx.z;
     const int ho0 = tile * g.TH;
     const int h_in0 = ho0 * STRIDE - 1;
-    float* ring = lds;                                  // 4 slots
-    float* redbuf = lds + 4 * (size_t)g.slot;           // 256*2 floats
+    float* ring = lds;                                  // 2 slots
+    float* redbuf = lds + 2 * (size_t)g.slot;           // 256*2 floats
 
-    // zero the whole ring once (halo columns stay zero for the entire march)
-    for (int i = tid; i < 4 * g.slot; i += 256) ring[i] = 0.f;
+    for (int i = tid; i < 2 * g.slot; i += 256) ring[i] = 0.f;   // halo columns stay zero
 
-    // item of this thread
     const bool active = tid < g.cpb * g.ipc;
     const int cc = active ? tid / g.ipc : 0;
     const int ri = active ? tid - cc * g.ipc : 0;
@@ -149,65 +166,90 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
 #pragma unroll
     for (int k = 0; k < 27; ++k) wt[k] = valid ? A.w[(size_t)c * 27 + k] : 0.f;
 
+    Chunk ch[NCH];
+    make_chunks<NCH>(g, n, c0, h_in0, g.H, g.W, A.pre, ch);
+    const float* xb = A.x + (size_t)n * g.C * g.T * g.H * g.W;
+    const int plane = g.H * g.W;
+    const bool vec = (g.W & 3) == 0;
+
     float4 reg[NCH];
     __syncthreads();
-    // prologue: planes 0 and 1 (plane -1 is all zero: slot 3 stays zero)
-    fwd_fetch<NCH>(A, n, c0, h_in0, 0, reg);
-    fwd_store<NCH>(A, n, c0, h_in0, 0, ring + 0 * (size_t)g.slot, reg);
-    fwd_fetch<NCH>(A, n, c0, h_in0, 1, reg);
-    fwd_store<NCH>(A, n, c0, h_in0, 1, ring + 1 * (size_t)g.slot, reg);
+    fetch4<NCH>(xb, ch, 0, true, vec, reg);
+    store_act<NCH>(ring, ch, true, A.pre_act, reg);
+    fetch4<NCH>(xb, ch, plane, g.T > 1, vec, reg);
+    store_act<NCH>(ring + g.slot, ch, g.T > 1, A.pre_act, reg);
     __syncthreads();
 
-    float s1 = 0.f, s2 = 0.f;
-    const int lrow = row * STRIDE;                       // first staged row used by this item
-    const int lcol = DW_PADL + grp * 4 * STRIDE - 1;     // first staged column used (w = -1 at PADL-1)
-    const size_t ybase = (((size_t)n * g.C + c) * g.T) * (size_t)g.Ho * g.Wo + (size_t)(ho0 + row) * g.Wo + grp * 4;
+    // LDS offset of this thread's first window element
+    const int woff = cc * g.IH * g.WP + (row * STRIDE) * g.WP + DW_PADL + grp * 4 * STRIDE - 1;
+    auto read_plane = [&](const float* slot, float (&v)[NV]) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const float* rp = slot + woff + kh * g.WP;
+            if (STRIDE == 1) {
+                v[kh * 6] = rp[0];
+                const float4 m = *reinterpret_cast<const float4*>(rp + 1);
+                v[kh * 6 + 1] = m.x; v[kh * 6 + 2] = m.y; v[kh * 6 + 3] = m.z; v[kh * 6 + 4] = m.w;
+                v[kh * 6 + 5] = rp[5];
+            } else {
+                v[kh * 9] = rp[0];
+                const float4 a = *reinterpret_cast<const float4*>(rp + 1);
+                const float4 b = *reinterpret_cast<const float4*>(rp + 5);
+                v[kh * 9 + 1] = a.x; v[kh * 9 + 2] = a.y; v[kh * 9 + 3] = a.z; v[kh * 9 + 4] = a.w;
+                v[kh * 9 + 5] = b.x; v[kh * 9 + 6] = b.y; v[kh * 9 + 7] = b.z; v[kh * 9 + 8] = b.w;
+            }
+        }
+    };
 
-    for (int t = 0; t < g.T; ++t) {
-        fwd_fetch<NCH>(A, n, c0, h_in0, t + 2, reg);     // in flight during the stencil
+    float s1 = 0.f, s2 = 0.f;
+    const size_t ybase = (((size_t)n * g.C + c) * g.T) * (size_t)g.Ho * g.Wo + (size_t)(ho0 + row) * g.Wo + grp * 4;
+    const bool vecy = (g.Wo & 3) == 0;
+
+    // one T step: window planes (wa, wb, wc) = (t-1, t, t+1)
+    auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
+        fetch4<NCH>(xb, ch, (t + 2) * plane, t + 2 < g.T, vec, reg);    // in flight during the stencil
         if (valid) {
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+            read_plane(ring + (size_t)((t + 1) & 1) * g.slot, wc);
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
-                const float* sl = ring + (size_t)((t + kt + 3) & 3) * g.slot + (size_t)cc * g.IH * g.WP;   // plane t-1+kt
+                const float(&v)[NV] = kt == 0 ? wa : (kt == 1 ? wb : wc);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
-                    const float* rp = sl + (size_t)(lrow + kh) * g.WP + lcol;
                     const float w0 = wt[kt * 9 + kh * 3], w1 = wt[kt * 9 + kh * 3 + 1], w2 = wt[kt * 9 + kh * 3 + 2];
-                    if (STRIDE == 1) {
-                        const float v0 = rp[0];
-                        const float4 m = *reinterpret_cast<const float4*>(rp + 1);
-                        const float v5 = rp[5];
-                        o0 = fmaf(w0, v0, fmaf(w1, m.x, fmaf(w2, m.y, o0)));
-                        o1 = fmaf(w0, m.x, fmaf(w1, m.y, fmaf(w2, m.z, o1)));
-                        o2 = fmaf(w0, m.y, fmaf(w1, m.z, fmaf(w2, m.w, o2)));
-                        o3 = fmaf(w0, m.z, fmaf(w1, m.w, fmaf(w2, v5, o3)));
-                    } else {
-                        const float v0 = rp[0];
-                        const float4 a = *reinterpret_cast<const float4*>(rp + 1);
-                        const float4 b = *reinterpret_cast<const float4*>(rp + 5);
-                        o0 = fmaf(w0, v0, fmaf(w1, a.x, fmaf(w2, a.y, o0)));
-                        o1 = fmaf(w0, a.y, fmaf(w1, a.z, fmaf(w2, a.w, o1)));
-                        o2 = fmaf(w0, a.w, fmaf(w1, b.x, fmaf(w2, b.y, o2)));
-                        o3 = fmaf(w0, b.y, fmaf(w1, b.z, fmaf(w2, b.w, o3)));
-                    }
+                    constexpr int RS = (STRIDE == 1) ? 6 : 9;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        o[i] = fmaf(w0, v[kh * RS + i * STRIDE], fmaf(w1, v[kh * RS + i * STRIDE + 1],
+                                    fmaf(w2, v[kh * RS + i * STRIDE + 2], o[i])));
                 }
             }
             float* py = A.y + ybase + (size_t)t * g.Ho * g.Wo;
             const int wo = grp * 4;
-            if ((g.Wo & 3) == 0) {
-                *reinterpret_cast<float4*>(py) = make_float4(o0, o1, o2, o3);
+            if (vecy) {
+                *reinterpret_cast<float4*>(py) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
-                py[0] = o0;
-                if (wo + 1 < g.Wo) py[1] = o1; else o1 = 0.f;
-                if (wo + 2 < g.Wo) py[2] = o2; else o2 = 0.f;
-                if (wo + 3 < g.Wo) py[3] = o3; else o3 = 0.f;
+                py[0] = o[0];
+                if (wo + 1 < g.Wo) py[1] = o[1]; else o[1] = 0.f;
+                if (wo + 2 < g.Wo) py[2] = o[2]; else o[2] = 0.f;
+                if (wo + 3 < g.Wo) py[3] = o[3]; else o[3] = 0.f;
             }
-            s1 += (o0 + o1) + (o2 + o3);
-            s2 = fmaf(o0, o0, fmaf(o1, o1, fmaf(o2, o2, fmaf(o3, o3, s2))));
+            s1 += (o[0] + o[1]) + (o[2] + o[3]);
+            s2 = fmaf(o[0], o[0], fmaf(o[1], o[1], fmaf(o[2], o[2], fmaf(o[3], o[3], s2))));
         }
-        fwd_store<NCH>(A, n, c0, h_in0, t + 2, ring + (size_t)((t + 2) & 3) * g.slot, reg);
+        // slot t&1 held plane t, last read one barrier ago -> free for plane t+2
+        store_act<NCH>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, A.pre_act, reg);
         __syncthreads();
+    };
+
+    float w0[NV], w1[NV], w2[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { w0[i] = 0.f; w1[i] = 0.f; w2[i] = 0.f; }
+    if (valid) read_plane(ring, w1);                     // plane 0
+    for (int t = 0; t < g.T; t += 3) {
+        step(t, w0, w1, w2);
+        if (t + 1 < g.T) step(t + 1, w1, w2, w0);
+        if (t + 2 < g.T) step(t + 2, w2, w0, w1);
     }
 
     if (A.partial != nullptr) {
@@ -215,19 +257,20 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
         redbuf[tid * 2 + 1] = valid ? s2 : 0.f;
         __syncthreads();
         if (tid < g.cpb * 2) {
-            const int ch = tid >> 1, which = tid & 1;
-            if (c0 + ch < g.C) {
+            const int chn = tid >> 1, which = tid & 1;
+            if (c0 + chn < g.C) {
                 float s = 0.f;
-                for (int i = 0; i < g.ipc; ++i) s += redbuf[(ch * g.ipc + i) * 2 + which];
-                A.partial[(((size_t)n * g.C + c0 + ch) * g.tiles + tile) * 2 + which] = s;
+                for (int i = 0; i < g.ipc; ++i) s += redbuf[(chn * g.ipc + i) * 2 + which];
+                A.partial[(((size_t)n * g.C + c0 + chn) * g.tiles + tile) * 2 + which] = s;
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// Fused backward.  Thread grid = INPUT voxels (4 consecutive w per thread); the ring holds
-// dY = cb0*g + cb1*a + cb2 at OUTPUT resolution, zero outside the tensor.
+// Fused backward.  Thread grid = INPUT voxels (4 consecutive w per thread); the LDS planes hold
+// dY = cb0*g + cb1*a + cb2 at OUTPUT resolution, zero outside the tensor.  Same double buffer +
+// register sliding window as the forward.
 // ---------------------------------------------------------------------------------------
 struct DwBwdArgs {
     const float* g; const float* a; const float* cb; const float* w;
@@ -237,62 +280,20 @@ struct DwBwdArgs {
 };
 
 template <int NCH>
-__device__ __forceinline__ void bwd_fetch(const DwBwdArgs& A, int n, int c0, int ho_lo, int t, float4 (&rg)[NCH],
-                                          float4 (&ra)[NCH]) {
-    const DwGeom& g = A.geo;
-    const int w4n = g.WP / 4 - 2;
-    const int total = g.cpb * g.IH * w4n;
+__device__ __forceinline__ void store_dy(float* slot, const Chunk (&ch)[NCH], bool tvalid, const float (&k0)[NCH],
+                                         const float (&k1)[NCH], const float (&k2)[NCH], const float4 (&rg)[NCH],
+                                         const float4 (&ra)[NCH]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int idx = i * 256 + threadIdx.x;
-        float4 vg = make_float4(0.f, 0.f, 0.f, 0.f), va = vg;
-        if (idx < total && t >= 0 && t < g.T) {
-            const int cc = idx / (g.IH * w4n);
-            const int rem = idx - cc * (g.IH * w4n);
-            const int ih = rem / w4n, w4 = rem - ih * w4n;
-            const int c = c0 + cc, ho = ho_lo + ih, w = w4 * 4;
-            if (c < g.C && ho >= 0 && ho < g.Ho && w < g.Wo) {
-                const size_t off = ((((size_t)n * g.C + c) * g.T + t) * g.Ho + ho) * (size_t)g.Wo + w;
-                if ((g.Wo & 3) == 0) {
-                    vg = *reinterpret_cast<const float4*>(A.g + off);
-                    va = *reinterpret_cast<const float4*>(A.a + off);
-                } else {
-                    vg.x = A.g[off]; va.x = A.a[off];
-                    if (w + 1 < g.Wo) { vg.y = A.g[off + 1]; va.y = A.a[off + 1]; }
-                    if (w + 2 < g.Wo) { vg.z = A.g[off + 2]; va.z = A.a[off + 2]; }
-                    if (w + 3 < g.Wo) { vg.w = A.g[off + 3]; va.w = A.a[off + 3]; }
-                }
-            }
-        }
-        rg[i] = vg;
-        ra[i] = va;
-    }
-}
-
-// combine to dY and store into the slot (zero outside the tensor, including the w >= Wo tail of a chunk)
-template <int NCH>
-__device__ __forceinline__ void bwd_store(const DwBwdArgs& A, int n, int c0, int ho_lo, int t, float* slot,
-                                          const float4 (&rg)[NCH], const float4 (&ra)[NCH]) {
-    const DwGeom& g = A.geo;
-    const int w4n = g.WP / 4 - 2;
-    const int total = g.cpb * g.IH * w4n;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int idx = i * 256 + threadIdx.x;
-        if (idx < total) {
-            const int rowi = idx / w4n, w4 = idx - rowi * w4n;
-            const int cc = rowi / g.IH, ih = rowi - cc * g.IH;
-            const int c = c0 + cc, ho = ho_lo + ih, w = w4 * 4;
+        if (ch[i].loff >= 0) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < g.T && c < g.C && ho >= 0 && ho < g.Ho && w < g.Wo) {
-                const float* cb = A.cb + ((size_t)n * g.C + c) * 3;
-                const float k0 = cb[0], k1 = cb[1], k2 = cb[2];
-                v.x = fmaf(k0, rg[i].x, fmaf(k1, ra[i].x, k2));
-                if (w + 1 < g.Wo) v.y = fmaf(k0, rg[i].y, fmaf(k1, ra[i].y, k2));
-                if (w + 2 < g.Wo) v.z = fmaf(k0, rg[i].z, fmaf(k1, ra[i].z, k2));
-                if (w + 3 < g.Wo) v.w = fmaf(k0, rg[i].w, fmaf(k1, ra[i].w, k2));
+            if (tvalid && ch[i].goff >= 0) {
+                v.x = fmaf(k0[i], rg[i].x, fmaf(k1[i], ra[i].x, k2[i]));
+                if (ch[i].nval > 1) v.y = fmaf(k0[i], rg[i].y, fmaf(k1[i], ra[i].y, k2[i]));
+                if (ch[i].nval > 2) v.z = fmaf(k0[i], rg[i].z, fmaf(k1[i], ra[i].z, k2[i]));
+                if (ch[i].nval > 3) v.w = fmaf(k0[i], rg[i].w, fmaf(k1[i], ra[i].w, k2[i]));
             }
-            *reinterpret_cast<float4*>(slot + (size_t)rowi * g.WP + DW_PADL + w4 * 4) = v;
+            *reinterpret_cast<float4*>(slot + ch[i].loff) = v;
         }
     }
 }
@@ -300,6 +301,7 @@ __device__ __forceinline__ void bwd_store(const DwBwdArgs& A, int n, int c0, int
 template <int NCH, int STRIDE>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NV = (STRIDE == 1) ? 18 : 6;           // window values per plane
     const DwGeom& g = A.geo;
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, c0 = blockIdx.y * g.cpb, n = blockIdx.z;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     const int ho_lo = STRIDE == 1 ? h0 - 1 : h0 / 2 - 1;          // first staged output row
     float* ring = lds;
 
-    for (int i = tid; i < 4 * g.slot; i += 256) ring[i] = 0.f;
+    for (int i = tid; i < 2 * g.slot; i += 256) ring[i] = 0.f;
 
     const bool active = tid < g.cpb * g.ipc;
     const int cc = active ? tid / g.ipc : 0;
@@ -322,85 +324,131 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     float sc = 1.f, sh = 0.f;
     if (valid && A.pre != nullptr) { sc = A.pre[((size_t)n * g.C + c) * 2]; sh = A.pre[((size_t)n * g.C + c) * 2 + 1]; }
 
+    Chunk ch[NCH];
+    make_chunks<NCH>(g, n, c0, ho_lo, g.Ho, g.Wo, nullptr, ch);
+    float k0[NCH], k1[NCH], k2[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        k0[i] = k1[i] = k2[i] = 0.f;
+        if (ch[i].goff >= 0) {
+            const int cg = ch[i].goff / (g.T * g.Ho * g.Wo);
+            const float* cb = A.cb + ((size_t)n * g.C + cg) * 3;
+            k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
+        }
+    }
+    const size_t vol_o = (size_t)n * g.C * g.T * g.Ho * g.Wo;
+    const float* gb = A.g + vol_o;
+    const float* ab = A.a + vol_o;
+    const int plane_o = g.Ho * g.Wo;
+    const bool veco = (g.Wo & 3) == 0;
+
     float4 rg[NCH], ra[NCH];
     __syncthreads();
-    bwd_fetch<NCH>(A, n, c0, ho_lo, 0, rg, ra);
-    bwd_store<NCH>(A, n, c0, ho_lo, 0, ring + 0 * (size_t)g.slot, rg, ra);
-    bwd_fetch<NCH>(A, n, c0, ho_lo, 1, rg, ra);
-    bwd_store<NCH>(A, n, c0, ho_lo, 1, ring + 1 * (size_t)g.slot, rg, ra);
+    fetch4<NCH>(gb, ch, 0, true, veco, rg);
+    fetch4<NCH>(ab, ch, 0, true, veco, ra);
+    store_dy<NCH>(ring, ch, true, k0, k1, k2, rg, ra);
+    fetch4<NCH>(gb, ch, plane_o, g.T > 1, veco, rg);
+    fetch4<NCH>(ab, ch, plane_o, g.T > 1, veco, ra);
+    store_dy<NCH>(ring + g.slot, ch, g.T > 1, k0, k1, k2, rg, ra);
     __syncthreads();
+
+    // window layout.  stride 1: rows ho = h+1-kh (kh = 0,1,2) -> staged rows row+2-kh, 6 columns
+    // starting at wo = w0-1.  stride 2: rows with (h+1-kh) even: h even -> kh=1 (one row, slot 0 of the
+    // window), h odd -> kh=0 (slot 0) and kh=2 (slot 1); 3 columns wo = 2grp .. 2grp+2.
+    const int par = h & 1;
+    int roff0, roff1;                                    // LDS offsets of the window rows
+    if (STRIDE == 1) {
+        roff0 = cc * g.IH * g.WP + (row + 2) * g.WP + DW_PADL + w0 - 1;     // kh = 0; kh adds -WP
+        roff1 = 0;
+    } else {
+        const int hoA = par ? (h + 1) >> 1 : h >> 1;     // kh = 0 (odd h) or kh = 1 (even h)
+        const int hoB = (h - 1) >> 1;                    // kh = 2 (odd h only)
+        roff0 = cc * g.IH * g.WP + (hoA - ho_lo) * g.WP + DW_PADL + 2 * grp;
+        roff1 = cc * g.IH * g.WP + ((par ? hoB : hoA) - ho_lo) * g.WP + DW_PADL + 2 * grp;
+    }
+    auto read_plane = [&](const float* slot, float (&v)[NV]) {
+        if (STRIDE == 1) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* rp = slot + roff0 - kh * g.WP;
+                v[kh * 6] = rp[0];
+                const float4 m = *reinterpret_cast<const float4*>(rp + 1);
+                v[kh * 6 + 1] = m.x; v[kh * 6 + 2] = m.y; v[kh * 6 + 3] = m.z; v[kh * 6 + 4] = m.w;
+                v[kh * 6 + 5] = rp[5];
+            }
+        } else {
+            const float* ra_ = slot + roff0;
+            const float* rb_ = slot + roff1;
+            v[0] = ra_[0]; v[1] = ra_[1]; v[2] = ra_[2];
+            v[3] = rb_[0]; v[4] = rb_[1]; v[5] = rb_[2];
+        }
+    };
 
     float s1 = 0.f, s2 = 0.f;
     const size_t xbase = (((size_t)n * g.C + c) * g.T) * (size_t)g.H * g.W + (size_t)h * g.W + w0;
+    const bool vecx = (g.W & 3) == 0;
 
-    for (int t = 0; t < g.T; ++t) {
-        bwd_fetch<NCH>(A, n, c0, ho_lo, t + 2, rg, ra);
+    // window planes (wa, wb, wc) = dY planes (t-1, t, t+1); time tap kt uses plane t+1-kt
+    auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
+        fetch4<NCH>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, veco, rg);
+        fetch4<NCH>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, veco, ra);
         if (valid) {
-            // raw forward input of this thread's 4 voxels
             const float* px = A.x + xbase + (size_t)t * g.H * g.W;
             float xv[4] = {0.f, 0.f, 0.f, 0.f};
-            if ((g.W & 3) == 0) {
-                const float4 q = *reinterpret_cast<const float4*>(px);
-                xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+            if (vecx) {
+                const float4 qv = *reinterpret_cast<const float4*>(px);
+                xv[0] = qv.x; xv[1] = qv.y; xv[2] = qv.z; xv[3] = qv.w;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (w0 + i < g.W) xv[i] = px[i];
             }
+            read_plane(ring + (size_t)((t + 1) & 1) * g.slot, wc);
             float hin[4], dact[4], d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float s = fmaf(sc, xv[i], sh);
+                const float sv = fmaf(sc, xv[i], sh);
                 const bool in = (w0 + i) < g.W;
-                hin[i] = in ? act_fwd(s, A.pre_act) : 0.f;
-                dact[i] = in ? act_bwd(s, A.pre_act) : 0.f;
+                hin[i] = in ? act_fwd(sv, A.pre_act) : 0.f;
+                dact[i] = in ? act_bwd(sv, A.pre_act) : 0.f;
             }
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
-                // plane index tp = t + 1 - kt  -> slot (tp & 3)
-                const float* sl = ring + (size_t)((t + 1 - kt + 4) & 3) * g.slot + (size_t)cc * g.IH * g.WP;
+                const float(&v)[NV] = kt == 0 ? wc : (kt == 1 ? wb : wa);
                 if (STRIDE == 1) {
 #pragma unroll
                     for (int kh = 0; kh < 3; ++kh) {
-                        // output row ho = h + 1 - kh -> staged row (ho - ho_lo) = row + 2 - kh
-                        const float* rp = sl + (size_t)(row + 2 - kh) * g.WP + DW_PADL + w0 - 1;
-                        float v[6];
-                        v[0] = rp[0];
-                        const float4 m = *reinterpret_cast<const float4*>(rp + 1);
-                        v[1] = m.x; v[2] = m.y; v[3] = m.z; v[4] = m.w;
-                        v[5] = rp[5];
-                        // wo = w + 1 - kw  ->  v index = i + 2 - kw
 #pragma unroll
                         for (int kw = 0; kw < 3; ++kw) {
                             const float wk = wt[kt * 9 + kh * 3 + kw];
                             float acc = dwacc[kt * 9 + kh * 3 + kw];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                d[i] = fmaf(wk, v[i + 2 - kw], d[i]);
-                                acc = fmaf(hin[i], v[i + 2 - kw], acc);
+                                d[i] = fmaf(wk, v[kh * 6 + i + 2 - kw], d[i]);
+                                acc = fmaf(hin[i], v[kh * 6 + i + 2 - kw], acc);
                             }
                             dwacc[kt * 9 + kh * 3 + kw] = acc;
                         }
                     }
                 } else {
-                    // stride 2: (h + 1 - kh) must be even.  h even -> kh = 1; h odd -> kh in {0, 2}
-                    // columns: staged cols for wo = 2*grp, 2*grp+1, 2*grp+2
-                    const int par = h & 1;
+                    // window slot 0: kh = par ? 0 : 1; window slot 1 (odd h only): kh = 2
 #pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) {
-                        if (((kh + 1) & 1) == par) {     // (h + 1 - kh) even  <=>  (kh+1) parity == h parity
-                            const int ho = (h + 1 - kh) >> 1;
-                            const float* rp = sl + (size_t)(ho - ho_lo) * g.WP + DW_PADL + 2 * grp;
-                            const float u0 = rp[0], u1 = rp[1], u2 = rp[2];
-                            const float k0 = wt[kt * 9 + kh * 3], k1 = wt[kt * 9 + kh * 3 + 1], k2 = wt[kt * 9 + kh * 3 + 2];
-                            // i=0 (w even): kw=1, wo=2grp ; i=1: kw=0 -> wo=2grp+1, kw=2 -> wo=2grp
-                            // i=2: kw=1, wo=2grp+1      ; i=3: kw=0 -> wo=2grp+2, kw=2 -> wo=2grp+1
-                            d[0] = fmaf(k1, u0, d[0]);
-                            d[1] = fmaf(k0, u1, fmaf(k2, u0, d[1]));
-                            d[2] = fmaf(k1, u1, d[2]);
-                            d[3] = fmaf(k0, u2, fmaf(k2, u1, d[3]));
-                            dwacc[kt * 9 + kh * 3] = fmaf(hin[1], u1, fmaf(hin[3], u2, dwacc[kt * 9 + kh * 3]));
-                            dwacc[kt * 9 + kh * 3 + 1] = fmaf(hin[0], u0, fmaf(hin[2], u1, dwacc[kt * 9 + kh * 3 + 1]));
-                            dwacc[kt * 9 + kh * 3 + 2] = fmaf(hin[1], u0, fmaf(hin[3], u1, dwacc[kt * 9 + kh * 3 + 2]));
+                    for (int sl = 0; sl < 2; ++sl) {
+                        if (sl == 0 || par) {
+                            const float u0 = v[sl * 3], u1 = v[sl * 3 + 1], u2 = v[sl * 3 + 2];
+#pragma unroll
+                            for (int khc = 0; khc < 3; ++khc) {
+                                const bool use = sl == 0 ? (khc == (par ? 0 : 1)) : (khc == 2);
+                                if (use) {
+                                    const float q0 = wt[kt * 9 + khc * 3], q1 = wt[kt * 9 + khc * 3 + 1], q2 = wt[kt * 9 + khc * 3 + 2];
+                                    d[0] = fmaf(q1, u0, d[0]);
+                                    d[1] = fmaf(q0, u1, fmaf(q2, u0, d[1]));
+                                    d[2] = fmaf(q1, u1, d[2]);
+                                    d[3] = fmaf(q0, u2, fmaf(q2, u1, d[3]));
+                                    dwacc[kt * 9 + khc * 3] = fmaf(hin[1], u1, fmaf(hin[3], u2, dwacc[kt * 9 + khc * 3]));
+                                    dwacc[kt * 9 + khc * 3 + 1] = fmaf(hin[0], u0, fmaf(hin[2], u1, dwacc[kt * 9 + khc * 3 + 1]));
+                                    dwacc[kt * 9 + khc * 3 + 2] = fmaf(hin[1], u0, fmaf(hin[3], u1, dwacc[kt * 9 + khc * 3 + 2]));
+                                }
+                            }
                         }
                     }
                 }
@@ -413,15 +461,25 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
                 s2 = fmaf(o[i], xv[i], s2);
             }
             float* po = A.out + xbase + (size_t)t * g.H * g.W;
-            if ((g.W & 3) == 0) {
+            if (vecx) {
                 *reinterpret_cast<float4*>(po) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (w0 + i < g.W) po[i] = o[i];
             }
         }
-        bwd_store<NCH>(A, n, c0, ho_lo, t + 2, ring + (size_t)((t + 2) & 3) * g.slot, rg, ra);
+        store_dy<NCH>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, k0, k1, k2, rg, ra);
         __syncthreads();
+    };
+
+    float wv0[NV], wv1[NV], wv2[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { wv0[i] = 0.f; wv1[i] = 0.f; wv2[i] = 0.f; }
+    if (valid) read_plane(ring, wv1);                    // dY plane 0
+    for (int t = 0; t < g.T; t += 3) {
+        step(t, wv0, wv1, wv2);
+        if (t + 1 < g.T) step(t + 1, wv1, wv2, wv0);
+        if (t + 2 < g.T) step(t + 2, wv2, wv0, wv1);
     }
 
     // reductions: per channel of the block, over its ipc items, in item order
@@ -432,20 +490,20 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     rb[28 * 256 + tid] = valid ? s2 : 0.f;
     __syncthreads();
     for (int o = tid; o < g.cpb * 29; o += 256) {
-        const int ch = o / 29, k = o - ch * 29;
-        if (c0 + ch < g.C) {
+        const int chn = o / 29, k = o - chn * 29;
+        if (c0 + chn < g.C) {
             float s = 0.f;
-            for (int i = 0; i < g.ipc; ++i) s += rb[k * 256 + ch * g.ipc + i];
-            const size_t row_id = ((size_t)n * g.C + c0 + ch) * g.tiles + tile;
-            if (k < 27) A.wpartial[(((size_t)n * g.tiles + tile) * g.C + c0 + ch) * 27 + k] = s;   // [N][tiles][C][27]
+            for (int i = 0; i < g.ipc; ++i) s += rb[k * 256 + chn * g.ipc + i];
+            const size_t row_id = ((size_t)n * g.C + c0 + chn) * g.tiles + tile;
+            if (k < 27) A.wpartial[(((size_t)n * g.tiles + tile) * g.C + c0 + chn) * 27 + k] = s;   // [N][tiles][C][27]
             else if (A.partial != nullptr) A.partial[row_id * 2 + (k - 27)] = s;
         }
     }
 }
 
-static size_t fwd_lds_bytes(const DwGeom& g) { return (4 * (size_t)g.slot + 512) * sizeof(float); }
+static size_t fwd_lds_bytes(const DwGeom& g) { return (2 * (size_t)g.slot + 512) * sizeof(float); }
 static size_t bwd_lds_bytes(const DwGeom& g) {
-    size_t ring = 4 * (size_t)g.slot, red = 29 * 256;
+    size_t ring = 2 * (size_t)g.slot, red = 29 * 256;
     return (ring > red ? ring : red) * sizeof(float);
 }
 static int nch_for(const DwGeom& g) { return cdiv(g.cpb * g.IH * (g.WP / 4 - 2), 256); }
