@@ -130,6 +130,15 @@ DW_CASES = [
     (1, 2, 3, 40, 56, 1),     # 3 row tiles
     (1, 2, 2, 58, 112, 2),    # wide stride-2 tile (layer1.0 geometry)
     (1, 2, 1, 9, 10, 1),      # T = 1
+    (2, 9, 2, 24, 24, 2),     # the (16,2,47) multigrid-like chain: T = 2, small planes
+    (2, 9, 2, 12, 12, 1),
+    (2, 20, 2, 6, 6, 2),
+    (2, 20, 2, 3, 3, 1),
+    (2, 40, 2, 3, 3, 2),
+    (2, 40, 2, 2, 2, 1),
+    (1, 3, 2, 56, 56, 1),     # one channel per workgroup (scalar-weight variant), T = 2
+    (1, 3, 4, 112, 112, 2),
+    (16, 108, 2, 6, 6, 1),    # many small workgroups (caught a slot-reuse race in the T march)
 ]
 
 

@@ -51,6 +51,7 @@ static DwGeom make_geom(int N, int C, int T, int H, int W, int stride, bool back
     g.tiles = cdiv(GH, th);
     const int SW = backward ? g.Wo : W;      // width of the staged tensor
     g.WP = ((SW + 3) / 4) * 4 + 8;
+    if (g.WP % 32 == 0) g.WP += 4;       // rows must not alias onto the same LDS banks
     if (!backward) g.IH = (th - 1) * stride + 3;
     else g.IH = stride == 1 ? th + 2 : th / 2 + 2;
     g.slot = cpb * g.IH * g.WP;
@@ -97,15 +98,15 @@ __device__ __forceinline__ void make_chunks(const DwGeom& g, int n, int c0, int 
     }
 }
 
-template <int NCH>
+template <int NCH, bool VEC>
 __device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chunk (&ch)[NCH], int toff, bool tvalid,
-                                       bool vec, float4 (&reg)[NCH]) {
+                                       float4 (&reg)[NCH]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tvalid && ch[i].goff >= 0) {
             const float* p = base + ch[i].goff + toff;
-            if (vec) {
+            if (VEC) {
                 v = *reinterpret_cast<const float4*>(p);
             } else {
                 v.x = p[0];
@@ -119,7 +120,7 @@ __device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chu
 }
 
 // activation applied while storing; everything outside the tensor is exact zero
-template <int NCH>
+template <int NCH, bool VEC>
 __device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], bool tvalid, int act,
                                           const float4 (&reg)[NCH]) {
 #pragma unroll
@@ -129,9 +130,9 @@ __device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], b
             if (tvalid && ch[i].goff >= 0) {
                 const float sc = ch[i].sc, sh = ch[i].sh;
                 v.x = act_fwd(fmaf(sc, reg[i].x, sh), act);
-                if (ch[i].nval > 1) v.y = act_fwd(fmaf(sc, reg[i].y, sh), act);
-                if (ch[i].nval > 2) v.z = act_fwd(fmaf(sc, reg[i].z, sh), act);
-                if (ch[i].nval > 3) v.w = act_fwd(fmaf(sc, reg[i].w, sh), act);
+                if (VEC || ch[i].nval > 1) v.y = act_fwd(fmaf(sc, reg[i].y, sh), act);
+                if (VEC || ch[i].nval > 2) v.z = act_fwd(fmaf(sc, reg[i].z, sh), act);
+                if (VEC || ch[i].nval > 3) v.w = act_fwd(fmaf(sc, reg[i].w, sh), act);
             }
             *reinterpret_cast<float4*>(slot + ch[i].loff) = v;
         }
@@ -141,7 +142,7 @@ __device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], b
 // Forward.  LDS holds two planes (double buffer); every thread keeps the values of the three
 // planes its stencil touches in registers (sliding window along T), so each staged value is
 // read from LDS once per consumer instead of three times.
-template <int NCH, int STRIDE>
+template <int NCH, int STRIDE, bool UNI, bool VEC>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NV = (STRIDE == 1) ? 18 : 27;          // window values per plane
@@ -155,29 +156,30 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
 
     for (int i = tid; i < 2 * g.slot; i += 256) ring[i] = 0.f;   // halo columns stay zero
 
+    // UNI: one channel per workgroup (large planes) -> channel index and the 27 taps are
+    // wave-uniform and live in scalar registers
     const bool active = tid < g.cpb * g.ipc;
-    const int cc = active ? tid / g.ipc : 0;
+    const int cc = (UNI || !active) ? 0 : tid / g.ipc;
     const int ri = active ? tid - cc * g.ipc : 0;
     const int row = ri / g.groups, grp = ri - row * g.groups;
-    const int c = c0 + cc;
+    const int c = UNI ? c0 : c0 + cc;
     const bool valid = active && c < g.C && (ho0 + row) < g.Ho;
 
     float wt[27];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) wt[k] = valid ? A.w[(size_t)c * 27 + k] : 0.f;
+    for (int k = 0; k < 27; ++k) wt[k] = UNI ? A.w[(size_t)c0 * 27 + k] : (valid ? A.w[(size_t)c * 27 + k] : 0.f);
 
     Chunk ch[NCH];
     make_chunks<NCH>(g, n, c0, h_in0, g.H, g.W, A.pre, ch);
     const float* xb = A.x + (size_t)n * g.C * g.T * g.H * g.W;
     const int plane = g.H * g.W;
-    const bool vec = (g.W & 3) == 0;
 
     float4 reg[NCH];
     __syncthreads();
-    fetch4<NCH>(xb, ch, 0, true, vec, reg);
-    store_act<NCH>(ring, ch, true, A.pre_act, reg);
-    fetch4<NCH>(xb, ch, plane, g.T > 1, vec, reg);
-    store_act<NCH>(ring + g.slot, ch, g.T > 1, A.pre_act, reg);
+    fetch4<NCH, VEC>(xb, ch, 0, true, reg);
+    store_act<NCH, VEC>(ring, ch, true, A.pre_act, reg);
+    fetch4<NCH, VEC>(xb, ch, plane, g.T > 1, reg);
+    store_act<NCH, VEC>(ring + g.slot, ch, g.T > 1, A.pre_act, reg);
     __syncthreads();
 
     // LDS offset of this thread's first window element
@@ -203,11 +205,10 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
 
     float s1 = 0.f, s2 = 0.f;
     const size_t ybase = (((size_t)n * g.C + c) * g.T) * (size_t)g.Ho * g.Wo + (size_t)(ho0 + row) * g.Wo + grp * 4;
-    const bool vecy = (g.Wo & 3) == 0;
 
     // one T step: window planes (wa, wb, wc) = (t-1, t, t+1)
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
-        fetch4<NCH>(xb, ch, (t + 2) * plane, t + 2 < g.T, vec, reg);    // in flight during the stencil
+        fetch4<NCH, VEC>(xb, ch, (t + 2) * plane, t + 2 < g.T, reg);    // in flight during the stencil
         if (valid) {
             read_plane(ring + (size_t)((t + 1) & 1) * g.slot, wc);
             float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
             }
             float* py = A.y + ybase + (size_t)t * g.Ho * g.Wo;
             const int wo = grp * 4;
-            if (vecy) {
+            if (VEC) {
                 *reinterpret_cast<float4*>(py) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
                 py[0] = o[0];
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
             s2 = fmaf(o[0], o[0], fmaf(o[1], o[1], fmaf(o[2], o[2], fmaf(o[3], o[3], s2))));
         }
         // slot t&1 held plane t, last read one barrier ago -> free for plane t+2
-        store_act<NCH>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, A.pre_act, reg);
+        store_act<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, A.pre_act, reg);
         __syncthreads();
     };
 
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) { w0[i] = 0.f; w1[i] = 0.f; w2[i] = 0.f; }
     if (valid) read_plane(ring, w1);                     // plane 0
+    __syncthreads();       // step 0 overwrites slot 0: every wave must have read plane 0 first
     for (int t = 0; t < g.T; t += 3) {
         step(t, w0, w1, w2);
         if (t + 1 < g.T) step(t + 1, w1, w2, w0);
@@ -279,7 +281,7 @@ struct DwBwdArgs {
     DwGeom geo;
 };
 
-template <int NCH>
+template <int NCH, bool VEC>
 __device__ __forceinline__ void store_dy(float* slot, const Chunk (&ch)[NCH], bool tvalid, const float (&k0)[NCH],
                                          const float (&k1)[NCH], const float (&k2)[NCH], const float4 (&rg)[NCH],
                                          const float4 (&ra)[NCH]) {
@@ -289,16 +291,16 @@ __device__ __forceinline__ void store_dy(float* slot, const Chunk (&ch)[NCH], bo
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (tvalid && ch[i].goff >= 0) {
                 v.x = fmaf(k0[i], rg[i].x, fmaf(k1[i], ra[i].x, k2[i]));
-                if (ch[i].nval > 1) v.y = fmaf(k0[i], rg[i].y, fmaf(k1[i], ra[i].y, k2[i]));
-                if (ch[i].nval > 2) v.z = fmaf(k0[i], rg[i].z, fmaf(k1[i], ra[i].z, k2[i]));
-                if (ch[i].nval > 3) v.w = fmaf(k0[i], rg[i].w, fmaf(k1[i], ra[i].w, k2[i]));
+                if (VEC || ch[i].nval > 1) v.y = fmaf(k0[i], rg[i].y, fmaf(k1[i], ra[i].y, k2[i]));
+                if (VEC || ch[i].nval > 2) v.z = fmaf(k0[i], rg[i].z, fmaf(k1[i], ra[i].z, k2[i]));
+                if (VEC || ch[i].nval > 3) v.w = fmaf(k0[i], rg[i].w, fmaf(k1[i], ra[i].w, k2[i]));
             }
             *reinterpret_cast<float4*>(slot + ch[i].loff) = v;
         }
     }
 }
 
-template <int NCH, int STRIDE>
+template <int NCH, int STRIDE, bool UNI, bool VEC>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NV = (STRIDE == 1) ? 18 : 6;           // window values per plane
@@ -312,17 +314,20 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     for (int i = tid; i < 2 * g.slot; i += 256) ring[i] = 0.f;
 
     const bool active = tid < g.cpb * g.ipc;
-    const int cc = active ? tid / g.ipc : 0;
+    const int cc = (UNI || !active) ? 0 : tid / g.ipc;
     const int ri = active ? tid - cc * g.ipc : 0;
     const int row = ri / g.groups, grp = ri - row * g.groups;
-    const int c = c0 + cc, h = h0 + row, w0 = grp * 4;
+    const int c = UNI ? c0 : c0 + cc, h = h0 + row, w0 = grp * 4;
     const bool valid = active && c < g.C && h < g.H;
 
     float wt[27], dwacc[27];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) { wt[k] = valid ? A.w[(size_t)c * 27 + k] : 0.f; dwacc[k] = 0.f; }
+    for (int k = 0; k < 27; ++k) {
+        wt[k] = UNI ? A.w[(size_t)c0 * 27 + k] : (valid ? A.w[(size_t)c * 27 + k] : 0.f);
+        dwacc[k] = 0.f;
+    }
     float sc = 1.f, sh = 0.f;
-    if (valid && A.pre != nullptr) { sc = A.pre[((size_t)n * g.C + c) * 2]; sh = A.pre[((size_t)n * g.C + c) * 2 + 1]; }
+    if (A.pre != nullptr && (UNI || valid)) { sc = A.pre[((size_t)n * g.C + c) * 2]; sh = A.pre[((size_t)n * g.C + c) * 2 + 1]; }
 
     Chunk ch[NCH];
     make_chunks<NCH>(g, n, c0, ho_lo, g.Ho, g.Wo, nullptr, ch);
@@ -340,16 +345,15 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     const float* gb = A.g + vol_o;
     const float* ab = A.a + vol_o;
     const int plane_o = g.Ho * g.Wo;
-    const bool veco = (g.Wo & 3) == 0;
 
     float4 rg[NCH], ra[NCH];
     __syncthreads();
-    fetch4<NCH>(gb, ch, 0, true, veco, rg);
-    fetch4<NCH>(ab, ch, 0, true, veco, ra);
-    store_dy<NCH>(ring, ch, true, k0, k1, k2, rg, ra);
-    fetch4<NCH>(gb, ch, plane_o, g.T > 1, veco, rg);
-    fetch4<NCH>(ab, ch, plane_o, g.T > 1, veco, ra);
-    store_dy<NCH>(ring + g.slot, ch, g.T > 1, k0, k1, k2, rg, ra);
+    fetch4<NCH, VEC>(gb, ch, 0, true, rg);
+    fetch4<NCH, VEC>(ab, ch, 0, true, ra);
+    store_dy<NCH, VEC>(ring, ch, true, k0, k1, k2, rg, ra);
+    fetch4<NCH, VEC>(gb, ch, plane_o, g.T > 1, rg);
+    fetch4<NCH, VEC>(ab, ch, plane_o, g.T > 1, ra);
+    store_dy<NCH, VEC>(ring + g.slot, ch, g.T > 1, k0, k1, k2, rg, ra);
     __syncthreads();
 
     // window layout.  stride 1: rows ho = h+1-kh (kh = 0,1,2) -> staged rows row+2-kh, 6 columns
@@ -386,16 +390,15 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
 
     float s1 = 0.f, s2 = 0.f;
     const size_t xbase = (((size_t)n * g.C + c) * g.T) * (size_t)g.H * g.W + (size_t)h * g.W + w0;
-    const bool vecx = (g.W & 3) == 0;
 
     // window planes (wa, wb, wc) = dY planes (t-1, t, t+1); time tap kt uses plane t+1-kt
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
-        fetch4<NCH>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, veco, rg);
-        fetch4<NCH>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, veco, ra);
+        fetch4<NCH, VEC>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, rg);
+        fetch4<NCH, VEC>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, ra);
         if (valid) {
             const float* px = A.x + xbase + (size_t)t * g.H * g.W;
             float xv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (vecx) {
+            if (VEC) {
                 const float4 qv = *reinterpret_cast<const float4*>(px);
                 xv[0] = qv.x; xv[1] = qv.y; xv[2] = qv.z; xv[3] = qv.w;
             } else {
@@ -461,14 +464,14 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
                 s2 = fmaf(o[i], xv[i], s2);
             }
             float* po = A.out + xbase + (size_t)t * g.H * g.W;
-            if (vecx) {
+            if (VEC) {
                 *reinterpret_cast<float4*>(po) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (w0 + i < g.W) po[i] = o[i];
             }
         }
-        store_dy<NCH>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, k0, k1, k2, rg, ra);
+        store_dy<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, k0, k1, k2, rg, ra);
         __syncthreads();
     };
 
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) { wv0[i] = 0.f; wv1[i] = 0.f; wv2[i] = 0.f; }
     if (valid) read_plane(ring, wv1);                    // dY plane 0
+    __syncthreads();       // step 0 overwrites slot 0: every wave must have read plane 0 first
     for (int t = 0; t < g.T; t += 3) {
         step(t, wv0, wv1, wv2);
         if (t + 1 < g.T) step(t + 1, wv1, wv2, wv0);
@@ -541,20 +545,28 @@ static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, h
     return X3D_OK;
 }
 
+#define DW_CASE(KERNEL, N_, S_)                                                                        \
+    (uni ? (vec ? dw_launch(KERNEL<N_, S_, true, true>, ARGS_, GEO_, LDSB_, s)                          \
+                : dw_launch(KERNEL<N_, S_, true, false>, ARGS_, GEO_, LDSB_, s))                        \
+         : (vec ? dw_launch(KERNEL<N_, S_, false, true>, ARGS_, GEO_, LDSB_, s)                         \
+                : dw_launch(KERNEL<N_, S_, false, false>, ARGS_, GEO_, LDSB_, s)))
+
 #define DW_DISPATCH(KERNEL, ARGS, GEO, LDSB)                                                          \
     do {                                                                                               \
-        const int nch = nch_for(GEO);                                                                  \
+        const auto& ARGS_ = ARGS; const DwGeom& GEO_ = GEO; const size_t LDSB_ = LDSB;                 \
+        const int nch = nch_for(GEO_);                                                                 \
+        const bool uni = GEO_.cpb == 1;                                                                \
+        const bool vec = (GEO_.W % 4 == 0) && (GEO_.Wo % 4 == 0);                                      \
         int rc_ = X3D_OK;                                                                              \
-        if ((GEO).stride == 1) {                                                                       \
-            if (nch <= 2) rc_ = dw_launch(KERNEL<2, 1>, ARGS, GEO, LDSB, s);                           \
-            else if (nch <= 4) rc_ = dw_launch(KERNEL<4, 1>, ARGS, GEO, LDSB, s);                      \
-            else if (nch <= 8) rc_ = dw_launch(KERNEL<8, 1>, ARGS, GEO, LDSB, s);                      \
-            else { x3d_set_error("dw333: row too wide (W=%d)", (GEO).W); return X3D_EINVAL; }          \
+        if (nch > 8) { x3d_set_error("dw333: row too wide (W=%d)", GEO_.W); return X3D_EINVAL; }       \
+        if (GEO_.stride == 1) {                                                                        \
+            if (nch <= 2) rc_ = DW_CASE(KERNEL, 2, 1);                                                 \
+            else if (nch <= 4) rc_ = DW_CASE(KERNEL, 4, 1);                                            \
+            else rc_ = DW_CASE(KERNEL, 8, 1);                                                          \
         } else {                                                                                       \
-            if (nch <= 2) rc_ = dw_launch(KERNEL<2, 2>, ARGS, GEO, LDSB, s);                           \
-            else if (nch <= 4) rc_ = dw_launch(KERNEL<4, 2>, ARGS, GEO, LDSB, s);                      \
-            else if (nch <= 8) rc_ = dw_launch(KERNEL<8, 2>, ARGS, GEO, LDSB, s);                      \
-            else { x3d_set_error("dw333: row too wide (W=%d)", (GEO).W); return X3D_EINVAL; }          \
+            if (nch <= 2) rc_ = DW_CASE(KERNEL, 2, 2);                                                 \
+            else if (nch <= 4) rc_ = DW_CASE(KERNEL, 4, 2);                                            \
+            else rc_ = DW_CASE(KERNEL, 8, 2);                                                          \
         }                                                                                              \
         if (rc_ != X3D_OK) return rc_;                                                                 \
     } while (0)
