@@ -49,17 +49,27 @@ const char* x3d_last_error(void);
  * downsample[0] :272; conv5 :231) as an fp32 MFMA GEMM  Y[co,p] = sum_ci W[co,ci] * in[ci,p].
  * ---------------------------------------------------------------------------------- */
 
-/* number of voxel tiles per sample the pw kernels use for `partial`: N samples, M = channels
- * of the tensor the partial sums describe (forward: Cout, backward-data: Cin), P = its T*H*W,
- * dense = 0 for the strided (downsample) forward, else 1 */
-int x3d_pw_tiles(int N, int M, int P, int dense);
+/* number of voxel tiles per sample the pw kernels use for `partial`: N samples, K = reduction
+ * channels (forward: Cin, backward-data: Cout), M = channels of the tensor the partial sums
+ * describe (forward: Cout, backward-data: Cin), P = its T*H*W, dense = 0 for the strided
+ * (downsample) forward, else 1 */
+int x3d_pw_tiles(int N, int K, int M, int P, int dense);
 
 /* Forward.  in[ci,p] = act(pre[n,ci,0] * x + pre[n,ci,1]) when pre != NULL (fuses the
  * producer's BN-apply + ReLU, or BN-apply * SE-scale + Swish: x3d.py:147-148,151-160), else x.
  * strideHW in {1,2}: 2 = the downsample conv's (1,2,2) stride (x3d.py:101), x is [N,Cin,T,H,W]
  * and y is [N,Cout,T,Ho,Wo].  partial (may be NULL) receives per-(n,co,tile) {sum y, sum y^2}
- * as float[N][Cout][x3d_pw_tiles(N,Cout,Po,strideHW==1)][2] for the BN that follows (x3d.py:51). */
-int x3d_pw_fwd(const float* x, const float* w, float* y,
+ * as float[N][Cout][x3d_pw_tiles(N,Cin,Cout,Po,strideHW==1)][2] for the BN that follows (x3d.py:51). */
+/* Weight pre-packing for the tiled variant used on large-C layers (K >= 64 and M >= 96, see
+ * x3d_pw_wants_packed): x3d_pw_pack writes w[Cout][Cin] into MFMA fragment order
+ * (x3d_pw_pack_floats(K, M) floats, zero padded); transposed = 1 packs the backward-data
+ * operand (M = Cin, K = Cout).  Weights change every optimizer step: pack once per step.
+ * Passing NULL for wpacked selects the streaming kernel (same results, same `partial` shape). */
+int x3d_pw_wants_packed(int K, int M);
+size_t x3d_pw_pack_floats(int K, int M);
+int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int transposed, void* stream);
+
+int x3d_pw_fwd(const float* x, const float* w, const float* wpacked, float* y,
                int N, int Cin, int Cout, int T, int H, int W, int strideHW,
                const float* pre, int pre_act,
                float* partial, void* stream);
@@ -76,6 +86,7 @@ int x3d_pw_fwd(const float* x, const float* w, float* y,
  * partial (NULL unless pre != NULL) gets per-(n,ci,tile) {sum out, sum out*x}.
  * Geometry: g,a are [N,Cout,T,H,W]; out,x are [N,Cin,T,H,W]. */
 int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float* w,
+                    const float* wpacked_t,
                     float* out, int N, int Cin, int Cout, int T, int H, int W,
                     const float* x, const float* pre, int pre_act,
                     const float* addend, int addend_stride,

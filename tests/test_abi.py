@@ -31,7 +31,8 @@ def test_library_loads_and_exports_every_symbol():
     exported = set(re.findall(r"\bT (x3d_[a-z0-9_]+)", out))
     assert set(_header_functions()) <= exported
     # pure host-side helpers are callable without a GPU
-    assert h.x3d_pw_tiles(1, 54, 1000, 1) == 16 and h.x3d_pw_tiles(64, 54, 100000, 1) == 391
+    assert h.x3d_pw_tiles(1, 24, 54, 1000, 1) == 16 and h.x3d_pw_tiles(64, 24, 54, 100000, 1) == 391
+    assert h.x3d_pw_tiles(8, 216, 96, 3136, 1) == 49
     assert h.x3d_ew_tiles(4097) == 3
     assert h.x3d_dw_tiles(56, 56) >= 1
     assert h.x3d_last_error() is not None

@@ -54,6 +54,11 @@ PW_CASES = [
     (1, 96, 432, 2, 5, 5, 1, 0),      # M 432 -> 4 M-blocks, scalar path
     (1, 192, 432, 4, 4, 4, 1, 0),
     (3, 48, 108, 4, 20, 20, 1, 0),    # 7 M-tiles
+    (2, 96, 216, 4, 12, 12, 1, 2),    # LDS-tiled variant: 9 voxel tiles, 14 M-tiles (2 blocks)
+    (2, 96, 192, 2, 9, 9, 2, 1),      # LDS-tiled variant, strided gather (layer4.0 downsample)
+    (2, 432, 192, 2, 7, 7, 1, 2),     # LDS-tiled variant, K = 432, P % 4 != 0
+    (1, 100, 130, 3, 6, 6, 1, 1),     # LDS-tiled, K % 4 == 0 but M not a multiple of 16
+    (1, 70, 98, 2, 6, 6, 1, 0),       # LDS-tiled, K % 4 != 0 (scalar weight staging)
 ]
 
 
@@ -67,12 +72,14 @@ def test_pw_fwd(case):
     pre = torch.stack([1 + 0.2 * _g(N, Ci, seed=3), 0.3 * _g(N, Ci, seed=4)], -1) if act else None
     xin = _act(pre[..., 0, None, None, None] * x + pre[..., 1, None, None, None], act) if act else x
     y_ref = xo.pw(xin, w.view(Co, Ci, 1, 1, 1), s)
-    y, partial = ops.pw_fwd(x.float().to(dev), w.float().to(dev), stride=s,
-                            pre=None if pre is None else pre.float().contiguous().to(dev), pre_act=act)
-    assert _rel(y, y_ref) < TOL
-    st = partial.double().sum(2).cpu()
-    assert _rel(st[..., 0], y_ref.sum(dim=(2, 3, 4))) < 5 * TOL + 1e-6
-    assert _rel(st[..., 1], (y_ref ** 2).sum(dim=(2, 3, 4))) < 5 * TOL
+    wd = w.float().to(dev)
+    for wp in (None, ops.pw_pack(wd)):          # streaming kernel, then (large layers) the tiled one
+        y, partial = ops.pw_fwd(x.float().to(dev), wd, stride=s,
+                                pre=None if pre is None else pre.float().contiguous().to(dev), pre_act=act, wp=wp)
+        assert _rel(y, y_ref) < TOL
+        st = partial.double().sum(2).cpu()
+        assert _rel(st[..., 0], y_ref.sum(dim=(2, 3, 4))) < 5 * TOL + 1e-6
+        assert _rel(st[..., 1], (y_ref ** 2).sum(dim=(2, 3, 4))) < 5 * TOL
 
 
 @pytest.mark.parametrize("case", PW_CASES)
@@ -99,8 +106,12 @@ def test_pw_bwd(case):
     if s == 1:
         addend = _g(N, Ci, T, H, W, seed=10)
         out_ref = (din_ref + addend) * (_dact(sx, act) if act else 1.0)
+        wpt = ops.pw_pack(to(w), transposed=True)
         out, partial = ops.pw_bwd_data(to(g), to(a), to(cb), to(w), x=to(x) if act else None, pre=to(pre),
                                        pre_act=act, addend=to(addend))
+        assert _rel(out, out_ref) < TOL
+        out, partial = ops.pw_bwd_data(to(g), to(a), to(cb), to(w), x=to(x) if act else None, pre=to(pre),
+                                       pre_act=act, addend=to(addend), wpt=wpt)
         assert _rel(out, out_ref) < TOL
         if act:
             st = partial.double().sum(2).cpu()
@@ -111,11 +122,11 @@ def test_pw_bwd(case):
         add2 = _g(N, Ci, T, H2, W2, seed=11)
         full = torch.zeros(N, Ci, T, H, W, dtype=torch.float64)
         full[:, :, :, ::2, ::2] = add2
-        out2, _ = ops.pw_bwd_data(to(g), to(a), to(cb), to(w), addend=to(add2), addend_stride=2)
+        out2, _ = ops.pw_bwd_data(to(g), to(a), to(cb), to(w), addend=to(add2), addend_stride=2, wpt=wpt)
         assert _rel(out2, din_ref + full) < TOL
     else:
         # strided forward: its backward-data is computed densely at output resolution
-        out, _ = ops.pw_bwd_data(to(g), to(a), to(cb), to(w))
+        out, _ = ops.pw_bwd_data(to(g), to(a), to(cb), to(w), wpt=ops.pw_pack(to(w), transposed=True))
         assert _rel(out, F.conv_transpose3d(dY, w.view(Co, Ci, 1, 1, 1))) < TOL
 
 

@@ -77,4 +77,4 @@ def test_graph_replay_equals_eager_and_torch_sgd():
     # the momentum buffer); longer trajectories diverge through fp32 ReLU flips (tests/parity.py)
     (l0, f0, _, _), (l2, f2, _, _) = [_run_mode(m, 2, sd, x, y, dev) for m in ("eager", "torch")]
     assert abs(l0 - l2) < 1e-3 * abs(l0)
-    assert ((f0 - f2).norm() / f2.norm()).item() < 2e-4
+    assert ((f0 - f2).norm() / f2.norm()).item() < 1e-3     # update size is ~0.15 relative per step

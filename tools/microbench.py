@@ -43,11 +43,12 @@ if which.startswith("pw"):
     w = torch.randn(Co, Ci, device=dev) / Ci ** 0.5
     pre = torch.rand(N, Ci, 2, device=dev)
     y = torch.empty(N, Co, T, H, W, device=dev)
-    us = t(lambda: ops.pw_fwd(x, w, pre=pre, pre_act=2, out=y))
+    wp = ops.pw_pack(w)
+    us = t(lambda: ops.pw_fwd(x, w, pre=pre, pre_act=2, out=y, wp=wp))
     fl = 2.0 * N * Ci * Co * T * H * W
     by = 4.0 * N * (Ci + Co) * T * H * W
     print("%s fwd(affine+swish): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
-    us = t(lambda: ops.pw_fwd(x, w, out=y))
+    us = t(lambda: ops.pw_fwd(x, w, out=y, wp=wp))
     print("%s fwd(raw): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
 elif which.startswith("dw"):
     shapes = {"dw_l1": (8, 54, 16, 56, 56, 1), "dw_l10": (8, 54, 16, 112, 112, 2), "dw_l2": (8, 108, 16, 28, 28, 1),

@@ -27,6 +27,7 @@ struct PwArgs {
     const float* a;       // IN_BNBWD: raw forward output [N][K][P]
     const float* cin;     // IN_AFFACT: [N][K][2];  IN_BNBWD: [N][K][3]
     const float* w;
+    const float* wp;      // weights pre-packed by x3d_pw_pack (tiled variant); may be NULL
     int w_ldk, w_ldm;     // weight element (k, m) at w[k*w_ldk + m*w_ldm]
     float* y;             // [N][M][P]
     int N, K, M, P;
@@ -286,9 +287,286 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Tiled variant for the large-C / small-P layers (stages 3-4, conv5): K >= 64, M >= 96.
+// Workgroup tile = up to 128 output channels x 64 voxels, K in chunks of 64 channels.
+//   * activations: staged ONCE per workgroup into a double-buffered LDS tile [64 ch][64 voxels]
+//     (global -> registers before the MFMAs of the current chunk, registers -> LDS after them,
+//     one barrier per chunk) with the prologue (BN apply / BN-backward combine / Swish) applied
+//     while staging; all four waves read the same fragments (ds_read_b128, 4 voxel tiles each);
+//   * weights: pre-packed once per step (x3d_pw_pack) into MFMA fragment order
+//     Wp[m-tile][k-group of 16][lane][4], zero padded, so a wave's A fragment for four k-steps is
+//     ONE fully coalesced 1-KiB global_load_dwordx4 from L2 with no bounds logic and no LDS.
+//   k index permutation: step e of lane group q uses channel 16*s + 4*q + e on both operands.
+// ---------------------------------------------------------------------------------------
+constexpr int P2_BN = 64, P2_KC = 64;
+constexpr int P2_NB = P2_KC * P2_BN / 4 / 256;      // activation float4 slots per thread
+constexpr int PW_MAXK = 640;   // per-sample input-coefficient table in LDS (XL: 630 channels)
+
+__global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, int K,
+                                                      int ldm, int ldk, int mtiles, int kgroups) {
+    // wp[((mt * kgroups + s) * 64 + lane) * 4 + e] = A[16 mt + (lane & 15)][16 s + 4 (lane >> 4) + e]
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= mtiles * kgroups * 256) return;
+    const int e = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+    const int s = blk % kgroups, mt = blk / kgroups;
+    const int row = 16 * mt + (lane & 15), k = 16 * s + 4 * (lane >> 4) + e;
+    wp[i] = (row < M && k < K) ? w[(size_t)row * ldm + (size_t)k * ldk] : 0.f;
+}
+
+template <int IN, int EPI, bool VEC>
+__global__ __launch_bounds__(256) void pw2_kernel(const PwArgs A) {
+    __shared__ __attribute__((aligned(16))) float Bl[2][P2_KC * P2_BN];
+    __shared__ float Cl[(IN == IN_RAW) ? 4 : 3 * PW_MAXK];
+    constexpr int NC = (IN == IN_BNBWD) ? 3 : 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int n = blockIdx.y;
+    const int tlo = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int mb = rest % A.mblocks, tile = (rest / A.mblocks) * 8 + tlo;
+    if (tile >= A.tiles) return;
+    const int mt_run = A.mt_run;                    // 16-row tiles in this M block (<= 8)
+    const int m0 = mb * mt_run * 16;
+    const int bm = min(mt_run * 16, A.M - m0);
+    const int p0 = tile * P2_BN;
+    const int K = A.K, P = A.P;
+    const int kgroups = (K + 15) / 16;
+
+    if (IN != IN_RAW) {
+        for (int i = tid; i < K * NC; i += 256) Cl[i] = A.cin[(size_t)n * K * NC + i];
+    }
+
+    // ---- activation staging descriptors (chunk-invariant) ----------------------------------
+    // 64 rows x 16 float4 columns = 1024 slots, four per thread
+    int brow[P2_NB], bcol[P2_NB], boff[P2_NB][VEC ? 1 : 4];
+    bool bval[P2_NB][VEC ? 1 : 4];
+#pragma unroll
+    for (int i = 0; i < P2_NB; ++i) {
+        const int slot = i * 256 + tid;
+        brow[i] = slot >> 4;
+        bcol[i] = (slot & 15) * 4;
+#pragma unroll
+        for (int e = 0; e < (VEC ? 1 : 4); ++e) {
+            const int p = p0 + bcol[i] + e;
+            bval[i][e] = p < P;
+            int off = p;
+            if (!VEC && IN != IN_BNBWD && A.strided && bval[i][e]) {
+                const int hw = A.Ho * A.Wo;
+                const int t = p / hw, rem = p - t * hw;
+                const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
+                off = (t * A.H + 2 * ho) * A.W + 2 * wo;
+            }
+            boff[i][e] = bval[i][e] ? off : 0;        // clamped: always a valid address
+        }
+    }
+    const float* xn = A.x + (size_t)n * K * (size_t)A.Pin;
+    const float* an = (IN == IN_BNBWD) ? A.a + (size_t)n * K * (size_t)P : nullptr;
+
+    float4 rb[P2_NB], rba[(IN == IN_BNBWD) ? P2_NB : 1];
+
+    // Branch-free fetch: every load is unconditional from a clamped address; predicates are
+    // applied when the registers are written to LDS (a load under a divergent branch makes the
+    // compiler wait for it before the next branch and serialises the burst on memory latency).
+    auto fetch = [&](int c) {
+        const int k0 = c * P2_KC;
+#pragma unroll
+        for (int i = 0; i < P2_NB; ++i) {
+            const int kc = min(k0 + brow[i], K - 1);
+            const float* px = xn + (size_t)kc * (size_t)A.Pin;
+            if (VEC) {
+                rb[i] = *reinterpret_cast<const float4*>(px + boff[i][0]);
+            } else {
+                rb[i] = make_float4(px[boff[i][0]], px[boff[i][1 % (VEC ? 1 : 4)]], px[boff[i][2 % (VEC ? 1 : 4)]],
+                                    px[boff[i][3 % (VEC ? 1 : 4)]]);
+            }
+            if (IN == IN_BNBWD) {
+                const float* pa = an + (size_t)kc * (size_t)P;
+                if (VEC) {
+                    rba[i] = *reinterpret_cast<const float4*>(pa + boff[i][0]);
+                } else {
+                    rba[i] = make_float4(pa[boff[i][0]], pa[boff[i][1 % (VEC ? 1 : 4)]], pa[boff[i][2 % (VEC ? 1 : 4)]],
+                                         pa[boff[i][3 % (VEC ? 1 : 4)]]);
+                }
+            }
+        }
+    };
+
+    auto store = [&](int c, int buf) {
+        const int k0 = c * P2_KC;
+#pragma unroll
+        for (int i = 0; i < P2_NB; ++i) {
+            const int k = k0 + brow[i];
+            const bool kv = k < K;
+            const int kc = kv ? k : 0;
+            bool ok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ok[e] = kv && bval[i][VEC ? 0 : e];
+            float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+            if (IN == IN_BNBWD) {
+                const float c0 = Cl[kc * 3], c1 = Cl[kc * 3 + 1], c2 = Cl[kc * 3 + 2];
+                const float av[4] = {rba[i].x, rba[i].y, rba[i].z, rba[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok[e] ? fmaf(c0, v[e], fmaf(c1, av[e], c2)) : 0.f;
+            } else if (IN == IN_AFFACT) {
+                const float sc = Cl[kc * 2], sh = Cl[kc * 2 + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok[e] ? act_fwd(fmaf(sc, v[e], sh), A.in_act) : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok[e] ? v[e] : 0.f;
+            }
+            *reinterpret_cast<float4*>(&Bl[buf][brow[i] * P2_BN + bcol[i]]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+
+    // this wave's M tiles: wave and wave + 4 (clamped to an existing tile: results of a clamped
+    // duplicate are simply never stored)
+    const int lt0 = min(wave, mt_run - 1), lt1 = min(wave + 4, mt_run - 1);
+    const float* wp0 = A.wp + ((size_t)(mb * mt_run + lt0) * kgroups) * 256 + lane * 4;
+    const float* wp1 = A.wp + ((size_t)(mb * mt_run + lt1) * kgroups) * 256 + lane * 4;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 a0[P2_KC / 16], a1[P2_KC / 16];
+    auto fetch_a = [&](int c) {
+#pragma unroll
+        for (int s4 = 0; s4 < P2_KC / 16; ++s4) {
+            const int sg = min(c * (P2_KC / 16) + s4, kgroups - 1);     // clamped; extra groups meet zero B rows
+            a0[s4] = *reinterpret_cast<const float4*>(wp0 + (size_t)sg * 256);
+            a1[s4] = *reinterpret_cast<const float4*>(wp1 + (size_t)sg * 256);
+        }
+    };
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int s4 = 0; s4 < P2_KC / 16; ++s4) {
+            const float av0[4] = {a0[s4].x, a0[s4].y, a0[s4].z, a0[s4].w};
+            const float av1[4] = {a1[s4].x, a1[s4].y, a1[s4].z, a1[s4].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 b = *reinterpret_cast<const float4*>(&Bl[buf][(s4 * 16 + 4 * q + e) * P2_BN + 4 * r]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], b.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], b.y, acc[0][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], b.z, acc[0][2], 0, 0, 0);
+                acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], b.w, acc[0][3], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.y, acc[1][1], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.z, acc[1][2], 0, 0, 0);
+                acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.w, acc[1][3], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nchunks = (K + P2_KC - 1) / P2_KC;
+    __syncthreads();            // Cl visible
+    fetch(0);
+    fetch_a(0);
+    store(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) fetch(c + 1);
+        compute(c & 1);
+        if (c + 1 < nchunks) { fetch_a(c + 1); store(c + 1, (c + 1) & 1); }
+        __syncthreads();
+    }
+
+    // ------------------------------ epilogue ------------------------------
+    const int pl = p0 + 4 * r;                      // this lane's first voxel
+    bool pv[4];
+    int aoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pv[j] = pl + j < P;
+        aoff[j] = -1;
+        if (EPI != EPI_STATS && A.addend != nullptr && pv[j]) {
+            const int p = pl + j;
+            if (A.addend_stride == 2) {
+                const int hw = A.H * A.W;
+                const int t = p / hw, rem = p - t * hw;
+                const int h = rem / A.W, w = rem - h * A.W;
+                if (!(h & 1) && !(w & 1)) aoff[j] = (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1);
+            } else {
+                aoff[j] = p;
+            }
+        }
+    }
+    const long long addP = (A.addend_stride == 2) ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lt = wave + 4 * i;
+        if (lt < mt_run) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = lt * 16 + 4 * q + e;
+                const int m = m0 + ml;
+                const bool mv = ml < bm;
+                float v[4] = {acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]};
+                float s1 = 0.f, s2 = 0.f;
+                if (mv && pv[0]) {
+                    float* py = A.y + ((size_t)n * A.M + m) * (size_t)P + pl;
+                    if (EPI != EPI_STATS && A.addend != nullptr) {
+                        const float* pa = A.addend + ((size_t)n * A.M + m) * (size_t)addP;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (aoff[j] >= 0) v[j] += pa[aoff[j]];
+                    }
+                    if (EPI == EPI_ACTBWD) {
+                        const float sc = A.ecoef[((size_t)n * A.M + m) * 2], sh = A.ecoef[((size_t)n * A.M + m) * 2 + 1];
+                        const float* px = A.ex + ((size_t)n * A.M + m) * (size_t)P + pl;
+                        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (VEC) {
+                            const float4 t4 = *reinterpret_cast<const float4*>(px);
+                            xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) if (pv[j]) xv[j] = px[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = pv[j] ? v[j] * act_bwd(fmaf(sc, xv[j], sh), A.e_act) : 0.f;
+                            s1 += v[j];
+                            s2 = fmaf(v[j], xv[j], s2);
+                        }
+                    } else if (EPI == EPI_STATS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+                    }
+                    if (VEC) {
+                        *reinterpret_cast<float4*>(py) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (pv[j]) py[j] = v[j];
+                    }
+                }
+                if (EPI != EPI_PLAIN && A.partial != nullptr) {
+                    s1 = row16_sum(s1);
+                    s2 = row16_sum(s2);
+                    if (r == 0 && mv) {
+                        A.partial[(((size_t)n * A.M + m) * A.tiles + tile) * 2] = s1;
+                        A.partial[(((size_t)n * A.M + m) * A.tiles + tile) * 2 + 1] = s2;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One decision function for kernel variant and tile count (the caller sizes `partial` with it).
-static void pw_plan(int N, int M, int P, bool dense, int* nt, int* tiles, int* mblocks, int* mt_run) {
+// variant: 0 = streaming NT=4, 1 = streaming NT=1, 2 = LDS-tiled (pw2)
+static void pw_plan(int N, int K, int M, int P, bool dense, int* variant, int* tiles, int* mblocks, int* mt_run) {
     const int mtiles = cdiv(M, 16);
+    if (K >= 64 && M >= 96) {
+        *variant = 2;
+        *mblocks = cdiv(mtiles, 8);
+        *mt_run = cdiv(mtiles, *mblocks);
+        *tiles = cdiv(P, P2_BN);
+        return;
+    }
     *mblocks = cdiv(mtiles, 4);
     *mt_run = cdiv(mtiles, *mblocks);
     int v = (dense && (P % 4 == 0)) ? 4 : 1;
@@ -296,20 +574,32 @@ static void pw_plan(int N, int M, int P, bool dense, int* nt, int* tiles, int* m
         const long long wgs = (long long)cdiv(P, 256) * N * (*mblocks);
         if (wgs < 1024) v = 1;      // small-P layers: 16 voxels per wave fills the chip (4x the waves)
     }
-    *nt = v;
+    *variant = v == 4 ? 0 : 1;
     *tiles = cdiv(P, 64 * v);
 }
 
 template <int IN, int EPI>
 int launch_pw(PwArgs& A, hipStream_t s) {
-    int nt;
-    pw_plan(A.N, A.M, A.P, !A.strided && (A.Pin % 4 == 0), &nt, &A.tiles, &A.mblocks, &A.mt_run);
+    int variant;
+    const bool dense = !A.strided && (A.Pin % 4 == 0);
+    pw_plan(A.N, A.K, A.M, A.P, dense, &variant, &A.tiles, &A.mblocks, &A.mt_run);
     dim3 grid(cdiv(A.tiles, 8) * 8 * A.mblocks, A.N), block(256);
-    if (A.mt_run <= 2) {
-        if (nt == 4) hipLaunchKernelGGL((pw_kernel<2, 4, IN, EPI>), grid, block, 0, s, A);
+    if (variant == 2 && A.wp == nullptr) {      // no packed weights: streaming kernel on the same 64-voxel tiles
+        variant = 1;
+        const int mtiles = cdiv(A.M, 16);
+        A.mblocks = cdiv(mtiles, 4);
+        A.mt_run = cdiv(mtiles, A.mblocks);
+        grid = dim3(cdiv(A.tiles, 8) * 8 * A.mblocks, A.N);
+    }
+    if (variant == 2) {
+        if (A.K > PW_MAXK) { x3d_set_error("pw: K=%d exceeds the coefficient table (%d)", A.K, PW_MAXK); return X3D_EINVAL; }
+        if (dense && (A.P % 4 == 0)) hipLaunchKernelGGL((pw2_kernel<IN, EPI, true>), grid, block, 0, s, A);
+        else hipLaunchKernelGGL((pw2_kernel<IN, EPI, false>), grid, block, 0, s, A);
+    } else if (A.mt_run <= 2) {
+        if (variant == 0) hipLaunchKernelGGL((pw_kernel<2, 4, IN, EPI>), grid, block, 0, s, A);
         else hipLaunchKernelGGL((pw_kernel<2, 1, IN, EPI>), grid, block, 0, s, A);
     } else {
-        if (nt == 4) hipLaunchKernelGGL((pw_kernel<4, 4, IN, EPI>), grid, block, 0, s, A);
+        if (variant == 0) hipLaunchKernelGGL((pw_kernel<4, 4, IN, EPI>), grid, block, 0, s, A);
         else hipLaunchKernelGGL((pw_kernel<4, 1, IN, EPI>), grid, block, 0, s, A);
     }
     X3D_LAUNCH_CHECK();
@@ -367,22 +657,25 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs A) {
 
     float4 ng[CT], na[CT], nx[IT];     // next step's raw loads
 
+    // Branch-free: unconditional loads from clamped (always valid) addresses; rows / voxels that
+    // do not exist are zeroed when the fragments are formed (a load under a divergent branch is
+    // waited for before the next branch, which would serialise the burst on memory latency).
     auto issue = [&](int n, int p) {   // p = first voxel of this lane's float4
-        const bool pin = p < P;
+        const int pc = VEC ? min(p, P - 4) : p;
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             if (i < ct_run) {
-                const size_t base = ((size_t)n * A.Co + co[i]) * (size_t)P + p;
+                const size_t rowb = ((size_t)n * A.Co + co[i]) * (size_t)P;
                 if (VEC) {
-                    ng[i] = (cov[i] && pin) ? *reinterpret_cast<const float4*>(A.g + base) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    na[i] = (cov[i] && pin) ? *reinterpret_cast<const float4*>(A.a + base) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    ng[i] = *reinterpret_cast<const float4*>(A.g + rowb + pc);
+                    na[i] = *reinterpret_cast<const float4*>(A.a + rowb + pc);
                 } else {
                     float tg[4], ta[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const bool ok = cov[i] && (p + e < P);
-                        tg[e] = ok ? A.g[base + e] : 0.f;
-                        ta[e] = ok ? A.a[base + e] : 0.f;
+                        const int pe = min(p + e, P - 1);
+                        tg[e] = A.g[rowb + pe];
+                        ta[e] = A.a[rowb + pe];
                     }
                     ng[i] = make_float4(tg[0], tg[1], tg[2], tg[3]);
                     na[i] = make_float4(ta[0], ta[1], ta[2], ta[3]);
@@ -394,24 +687,20 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs A) {
             if (j < it_run) {
                 const float* px = A.x + ((size_t)n * A.Ci + ci[j]) * (size_t)A.Pin;
                 if (VEC) {
-                    nx[j] = (civ[j] && pin) ? *reinterpret_cast<const float4*>(px + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    nx[j] = *reinterpret_cast<const float4*>(px + pc);
                 } else {
                     float tx[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int pp = p + e;
-                        float v = 0.f;
-                        if (civ[j] && pp < P) {
-                            if (A.strided) {
-                                const int hw = A.Ho * A.Wo;
-                                const int t = pp / hw, rem = pp - t * hw;
-                                const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
-                                v = px[(size_t)(t * A.H + 2 * ho) * A.W + 2 * wo];
-                            } else {
-                                v = px[pp];
-                            }
+                        const int pp = min(p + e, P - 1);
+                        size_t off = pp;
+                        if (A.strided) {
+                            const int hw = A.Ho * A.Wo;
+                            const int t = pp / hw, rem = pp - t * hw;
+                            const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
+                            off = (size_t)(t * A.H + 2 * ho) * A.W + 2 * wo;
                         }
-                        tx[e] = v;
+                        tx[e] = px[off];
                     }
                     nx[j] = make_float4(tx[0], tx[1], tx[2], tx[3]);
                 }
@@ -456,7 +745,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs A) {
                     xin[j].z = (civ[j] && pv[2]) ? act_fwd(fmaf(sc[j], nx[j].z, sh[j]), A.pre_act) : 0.f;
                     xin[j].w = (civ[j] && pv[3]) ? act_fwd(fmaf(sc[j], nx[j].w, sh[j]), A.pre_act) : 0.f;
                 } else {
-                    xin[j] = nx[j];
+                    xin[j].x = (civ[j] && pv[0]) ? nx[j].x : 0.f;
+                    xin[j].y = (civ[j] && pv[1]) ? nx[j].y : 0.f;
+                    xin[j].z = (civ[j] && pv[2]) ? nx[j].z : 0.f;
+                    xin[j].w = (civ[j] && pv[3]) ? nx[j].w : 0.f;
                 }
             }
             if (st + 1 < WG_UNIT / 16) issue(n, p + 16);      // prefetch the next step
@@ -543,21 +835,39 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int x3d_pw_tiles(int N, int M, int P, int dense) {
-    int nt, tiles, mb, mt;
-    pw_plan(N, M, P, dense != 0, &nt, &tiles, &mb, &mt);
+extern "C" int x3d_pw_tiles(int N, int K, int M, int P, int dense) {
+    int variant, tiles, mb, mt;
+    pw_plan(N, K, M, P, dense != 0, &variant, &tiles, &mb, &mt);
     return tiles;
 }
 
-extern "C" int x3d_pw_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout, int T, int H,
-                          int W, int strideHW, const float* pre, int pre_act, float* partial, void* stream) {
+extern "C" int x3d_pw_wants_packed(int K, int M) { return (K >= 64 && M >= 96) ? 1 : 0; }
+
+extern "C" size_t x3d_pw_pack_floats(int K, int M) { return (size_t)cdiv(M, 16) * cdiv(K, 16) * 256; }
+
+extern "C" int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int transposed, void* stream) {
+    X3D_CHECK_ARG(w && wp && Cout > 0 && Cin > 0);
+    // forward:    A[row = co][k = ci] = w[co*Cin + ci]   (M = Cout, K = Cin)
+    // transposed: A[row = ci][k = co] = w[co*Cin + ci]   (M = Cin,  K = Cout)   (backward-data)
+    const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
+    const int ldm = transposed ? 1 : Cin, ldk = transposed ? Cin : 1;
+    const int mtiles = cdiv(M, 16), kgroups = cdiv(K, 16);
+    hipLaunchKernelGGL(pw_pack_kernel, dim3(cdiv(mtiles * kgroups * 256, 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                       M, K, ldm, ldk, mtiles, kgroups);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_pw_fwd(const float* x, const float* w, const float* wpacked, float* y, int N, int Cin, int Cout,
+                          int T, int H, int W, int strideHW, const float* pre, int pre_act, float* partial,
+                          void* stream) {
     X3D_CHECK_ARG(x && w && y);
     X3D_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
     X3D_CHECK_ARG(N <= 65535);
     PwArgs A = {};
     const int Ho = strideHW == 2 ? (H - 1) / 2 + 1 : H, Wo = strideHW == 2 ? (W - 1) / 2 + 1 : W;
-    A.x = x; A.a = nullptr; A.cin = pre; A.w = w; A.w_ldk = 1; A.w_ldm = Cin; A.y = y;
+    A.x = x; A.a = nullptr; A.cin = pre; A.w = w; A.wp = wpacked; A.w_ldk = 1; A.w_ldm = Cin; A.y = y;
     A.N = N; A.K = Cin; A.M = Cout; A.P = T * Ho * Wo; A.Pin = (long long)T * H * W;
     A.in_act = pre_act; A.strided = strideHW == 2; A.T = T; A.H = H; A.W = W; A.Ho = Ho; A.Wo = Wo;
     A.partial = partial; A.addend = nullptr; A.addend_stride = 1;
@@ -566,7 +876,8 @@ extern "C" int x3d_pw_fwd(const float* x, const float* w, float* y, int N, int C
     return launch_pw<IN_RAW, EPI_STATS>(A, s);
 }
 
-extern "C" int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float* w, float* out,
+extern "C" int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float* w,
+                               const float* wpacked_t, float* out,
                                int N, int Cin, int Cout, int T, int H, int W, const float* x,
                                const float* pre, int pre_act, const float* addend, int addend_stride,
                                float* partial, void* stream) {
@@ -575,7 +886,7 @@ extern "C" int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, 
     X3D_CHECK_ARG(addend_stride == 1 || addend_stride == 2);
     X3D_CHECK_ARG((pre == nullptr) || (x != nullptr));
     PwArgs A = {};
-    A.x = g; A.a = a; A.cin = cb; A.w = w; A.w_ldk = Cin; A.w_ldm = 1; A.y = out;
+    A.x = g; A.a = a; A.cin = cb; A.w = w; A.wp = wpacked_t; A.w_ldk = Cin; A.w_ldm = 1; A.y = out;
     A.N = N; A.K = Cout; A.M = Cin; A.P = T * H * W; A.Pin = A.P;
     A.strided = 0; A.T = T; A.H = H; A.W = W;
     A.Ho = (H - 1) / 2 + 1; A.Wo = (W - 1) / 2 + 1;

@@ -24,9 +24,12 @@ _Z = ctypes.c_size_t
 SIGNATURES = {
     "x3d_abi_version": (_I, []),
     "x3d_last_error": (ctypes.c_char_p, []),
-    "x3d_pw_tiles": (_I, [_I, _I, _I, _I]),
-    "x3d_pw_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
-    "x3d_pw_bwd_data": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P]),
+    "x3d_pw_tiles": (_I, [_I, _I, _I, _I, _I]),
+    "x3d_pw_wants_packed": (_I, [_I, _I]),
+    "x3d_pw_pack_floats": (_Z, [_I, _I]),
+    "x3d_pw_pack": (_I, [_P, _P, _I, _I, _I, _P]),
+    "x3d_pw_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "x3d_pw_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P]),
     "x3d_pw_wgrad_groups": (_I, [_I, _I, _I, _I]),
     "x3d_pw_bwd_weight": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_reduce_partials": (_I, [_P, _P, _I, _I, _P]),

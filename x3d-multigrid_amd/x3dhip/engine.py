@@ -89,7 +89,8 @@ def trunk_forward(model, x, training, ctx=None):
             cur_raw, cur_coef = _block_forward(blk, cur_raw, cur_coef, S, training, ctx)
 
     # ---- conv5 / bn5 / relu / global average pool
-    a5, p5 = ops.pw_fwd(cur_raw, _w2d(model.conv5.weight), want_stats=training)
+    w5 = _w2d(model.conv5.weight)
+    a5, p5 = ops.pw_fwd(cur_raw, w5, want_stats=training, wp=ops.pw_pack(w5))
     P5 = a5[0, 0].numel()
     if training:
         c5, save5, _ = _bn_train(p5, model.bn5, S, P5)
@@ -97,7 +98,7 @@ def trunk_forward(model, x, training, ctx=None):
         c5, save5 = _bn_eval(model.bn5, N), None
     pooled = ops.bn_relu_pool_fwd(a5, c5)
     if ctx is not None:
-        ctx.head = dict(x4=cur_raw, a5=a5, c5=c5, save5=save5, S=S)
+        ctx.head = dict(x4=cur_raw, a5=a5, c5=c5, save5=save5, S=S, w5t=ops.pw_pack(w5, transposed=True))
     return pooled
 
 
@@ -105,7 +106,8 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx):
     N = x_raw.shape[0]
     pre_act = ACT_RELU if x_coef is not None else ACT_NONE
     stride = blk.stride
-    a1, p1 = ops.pw_fwd(x_raw, _w2d(blk.conv1.weight), pre=x_coef, pre_act=pre_act, want_stats=training)
+    w1, w3 = _w2d(blk.conv1.weight), _w2d(blk.conv3.weight)
+    a1, p1 = ops.pw_fwd(x_raw, w1, pre=x_coef, pre_act=pre_act, want_stats=training, wp=ops.pw_pack(w1))
     P1 = a1[0, 0].numel()
     if training:
         c1, s1, _ = _bn_train(p1, blk.bn1, S, P1)
@@ -128,15 +130,16 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx):
         se = dict(se=se_v, z=z, pool=pool, nsum=nsum2)
     else:
         c2e = c2
-    a3, p3 = ops.pw_fwd(a2, _w2d(blk.conv3.weight), pre=c2e, pre_act=ACT_SWISH, want_stats=training)
+    a3, p3 = ops.pw_fwd(a2, w3, pre=c2e, pre_act=ACT_SWISH, want_stats=training, wp=ops.pw_pack(w3))
     if training:
         c3, s3, _ = _bn_train(p3, blk.bn3, S, P2)
     else:
         c3, s3 = _bn_eval(blk.bn3, N), None
     ad = cd = sd = None
     if blk.downsample is not None:
-        ad, pd = ops.pw_fwd(x_raw, _w2d(blk.downsample[0].weight), stride=stride, pre=x_coef, pre_act=pre_act,
-                            want_stats=training)
+        wd = _w2d(blk.downsample[0].weight)
+        ad, pd = ops.pw_fwd(x_raw, wd, stride=stride, pre=x_coef, pre_act=pre_act, want_stats=training,
+                            wp=ops.pw_pack(wd))
         if training:
             cd, sd, _ = _bn_train(pd, blk.downsample[1], S, P2)
         else:
@@ -147,8 +150,12 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx):
             raise RuntimeError("identity residual needs a materialised block input")
         out = ops.bn_add_relu_fwd(a3, c3, x_raw, None)
     if ctx is not None:
+        # transposed packs for the backward-data GEMMs (weights are unchanged until the optimizer step)
         ctx.blocks.append(dict(blk=blk, x_raw=x_raw, x_coef=x_coef, a1=a1, c1=c1, s1=s1, a2=a2, c2e=c2e, s2=s2,
-                               se=se, a3=a3, s3=s3, ad=ad, sd=sd, out=out, S=S))
+                               se=se, a3=a3, s3=s3, ad=ad, sd=sd, out=out, S=S,
+                               w1t=ops.pw_pack(w1, transposed=True), w3t=ops.pw_pack(w3, transposed=True),
+                               wdt=ops.pw_pack(_w2d(blk.downsample[0].weight), transposed=True)
+                               if blk.downsample is not None else None))
     return out, None
 
 
@@ -182,7 +189,7 @@ def trunk_backward(model, ctx, dpooled, grads):
     _bn_bwd(grads, pp, S, P5, model.bn5, hd["save5"], out_cb=True)
     cb5 = grads.last_cb
     _wgrad(grads, model.conv5.weight, g5, a5, cb5, hd["x4"])
-    dcur, _ = ops.pw_bwd_data(g5, a5, cb5, _w2d(model.conv5.weight))
+    dcur, _ = ops.pw_bwd_data(g5, a5, cb5, _w2d(model.conv5.weight), wpt=hd["w5t"])
     del g5
 
     pstem = None
@@ -225,7 +232,8 @@ def _block_backward(rec, dout, grads):
 
     # conv3: weight gradient, then data gradient fused with the swish backward
     _wgrad(grads, blk.conv3.weight, g3, a3, cb3, a2, pre=rec["c2e"], pre_act=ACT_SWISH)
-    ds, ps = ops.pw_bwd_data(g3, a3, cb3, _w2d(blk.conv3.weight), x=a2, pre=rec["c2e"], pre_act=ACT_SWISH)
+    ds, ps = ops.pw_bwd_data(g3, a3, cb3, _w2d(blk.conv3.weight), x=a2, pre=rec["c2e"], pre_act=ACT_SWISH,
+                             wpt=rec["w3t"])
     if blk.has_se:
         se = rec["se"]
         outs = None
@@ -257,12 +265,12 @@ def _block_backward(rec, dout, grads):
         dsc, dsb = blk.downsample[0], blk.downsample[1]
         cbd = _bn_bwd(grads, pd, S, P2, dsb, rec["sd"])
         _wgrad(grads, dsc.weight, g3, ad, cbd, x_raw, stride=blk.stride, pre=x_coef, pre_act=pre_act)
-        addend, _ = ops.pw_bwd_data(g3, ad, cbd, _w2d(dsc.weight))
+        addend, _ = ops.pw_bwd_data(g3, ad, cbd, _w2d(dsc.weight), wpt=rec["wdt"])
         astride = blk.stride
     else:
         addend, astride = g3, 1
     dprev, pprev = ops.pw_bwd_data(g1, a1, cb1, _w2d(blk.conv1.weight), x=x_raw if x_coef is not None else None,
-                                   pre=x_coef, pre_act=pre_act, addend=addend, addend_stride=astride)
+                                   pre=x_coef, pre_act=pre_act, addend=addend, addend_stride=astride, wpt=rec["w1t"])
     return dprev, pprev
 
 

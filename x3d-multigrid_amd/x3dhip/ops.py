@@ -45,7 +45,20 @@ def finalize_scratch(dev, N, C, Wd=0):
 
 
 # ----------------------------------------------------------------------------- pointwise
-def pw_fwd(x, w, stride=1, pre=None, pre_act=ACT_NONE, want_stats=True, out=None, partial=None):
+def pw_pack(w, transposed=False):
+    """Pre-pack a [Cout, Cin] weight for the tiled pw kernel (None when the layer is too small
+    to use it).  transposed=True packs the backward-data operand."""
+    L = _lib.lib()
+    Cout, Cin = w.shape
+    K, M = (Cout, Cin) if transposed else (Cin, Cout)
+    if not L.x3d_pw_wants_packed(K, M):
+        return None
+    wp = _f((L.x3d_pw_pack_floats(K, M),), w)
+    check(L.x3d_pw_pack(ptr(w), ptr(wp), Cout, Cin, 1 if transposed else 0, _lib.stream()))
+    return wp
+
+
+def pw_fwd(x, w, stride=1, pre=None, pre_act=ACT_NONE, want_stats=True, out=None, partial=None, wp=None):
     _need_cuda(x, w, pre)
     L = _lib.lib()
     N, Cin, T, H, W = x.shape
@@ -53,22 +66,22 @@ def pw_fwd(x, w, stride=1, pre=None, pre_act=ACT_NONE, want_stats=True, out=None
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
     y = out if out is not None else _f((N, Cout, T, Ho, Wo), x)
     if want_stats and partial is None:
-        partial = _f((N, Cout, L.x3d_pw_tiles(N, Cout, T * Ho * Wo, 1 if stride == 1 else 0), 2), x)
-    check(L.x3d_pw_fwd(ptr(x), ptr(w), ptr(y), N, Cin, Cout, T, H, W, stride, ptr(pre), pre_act,
+        partial = _f((N, Cout, L.x3d_pw_tiles(N, Cin, Cout, T * Ho * Wo, 1 if stride == 1 else 0), 2), x)
+    check(L.x3d_pw_fwd(ptr(x), ptr(w), ptr(wp), ptr(y), N, Cin, Cout, T, H, W, stride, ptr(pre), pre_act,
                        ptr(partial) if want_stats else None, _lib.stream()))
     return y, (partial if want_stats else None)
 
 
 def pw_bwd_data(g, a, cb, w, x=None, pre=None, pre_act=ACT_NONE, addend=None, addend_stride=1,
-                out=None, partial=None):
+                out=None, partial=None, wpt=None):
     _need_cuda(g, a, cb, w, x, pre, addend)
     L = _lib.lib()
     N, Cout, T, H, W = g.shape
     Cin = w.shape[1]
     o = out if out is not None else _f((N, Cin, T, H, W), g)
     if pre is not None and partial is None:
-        partial = _f((N, Cin, L.x3d_pw_tiles(N, Cin, T * H * W, 1), 2), g)
-    check(L.x3d_pw_bwd_data(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(o), N, Cin, Cout, T, H, W, ptr(x), ptr(pre),
+        partial = _f((N, Cin, L.x3d_pw_tiles(N, Cout, Cin, T * H * W, 1), 2), g)
+    check(L.x3d_pw_bwd_data(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(wpt), ptr(o), N, Cin, Cout, T, H, W, ptr(x), ptr(pre),
                             pre_act, ptr(addend), addend_stride, ptr(partial) if pre is not None else None,
                             _lib.stream()))
     return o, (partial if pre is not None else None)
