@@ -165,9 +165,10 @@ class _GradSink:
     zeroed flat gradient buffer): kernels write straight into the existing .grad storage and
     autograd gets None -- 300+ tiny accumulate kernels per step disappear."""
 
-    def __init__(self, direct):
+    def __init__(self, direct, side=None):
         self.direct = direct
         self.written = {}
+        self.side = side          # HIP stream for the weight-gradient kernels (off the critical path)
 
     def out(self, p):
         if self.direct and p.grad is not None:
@@ -205,6 +206,8 @@ def trunk_backward(model, ctx, dpooled, grads):
     dx_s, dwt = ops.dw5t_bwd(dcur, a_t, cb0, w_t.data, st["a_s"], dw_out=grads.out(w_t))
     grads.put(w_t, dwt)
     grads.put(w_s, ops.stem133_bwd_weight(st["x"], dx_s, w_s.shape, out=grads.out(w_s)))
+    if grads.side is not None:
+        torch.cuda.current_stream().wait_stream(grads.side)
 
 
 def _bn_bwd(grads, partial, S, count, bn, save, out_cb=True):
@@ -216,8 +219,34 @@ def _bn_bwd(grads, partial, S, count, bn, save, out_cb=True):
     return cb
 
 
+_side_streams = {}
+
+
+def side_stream(device):
+    """One extra HIP stream per device for work that is off the backward critical path."""
+    st = _side_streams.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[device] = st
+    return st
+
+
 def _wgrad(grads, w, g, a, cb, x, **kw):
-    grads.put(w, ops.pw_bwd_weight(g, a, cb, x, w.shape, out=grads.out(w), **kw))
+    """Pointwise weight gradient.  Nothing downstream in the backward pass consumes it, so it runs
+    on the side stream, concurrently with the data-gradient chain (the small stage-3/4 kernels
+    cannot fill 256 CUs on their own); joined once at the end of trunk_backward."""
+    side = grads.side
+    if side is None:
+        grads.put(w, ops.pw_bwd_weight(g, a, cb, x, w.shape, out=grads.out(w), **kw))
+        return
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw = ops.pw_bwd_weight(g, a, cb, x, w.shape, out=grads.out(w), **kw)
+    for t in (g, a, cb, x, kw.get("pre")):
+        if t is not None:
+            t.record_stream(side)
+    grads.put(w, dw)
 
 
 def _block_backward(rec, dout, grads):
@@ -299,7 +328,7 @@ class TrunkFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpooled):
-        sink = _GradSink(getattr(ctx.model, "_direct_grads", False))
+        sink = _GradSink(getattr(ctx.model, "_direct_grads", False), side_stream(dpooled.device))
         trunk_backward(ctx.model, ctx.tctx, dpooled, sink)
         ctx.tctx = None
         out = []
