@@ -50,7 +50,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1 / (1 + e^-x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float act_fwd(float s, int act) {
     if (act == X3D_ACT_RELU) return s > 0.f ? s : 0.f;

@@ -20,6 +20,7 @@ namespace {
 
 enum { IN_RAW = 0, IN_AFFACT = 1, IN_BNBWD = 2 };
 enum { EPI_STATS = 0, EPI_PLAIN = 1, EPI_ACTBWD = 2 };
+constexpr int PW_MAXK = 640;   // per-sample input-coefficient table in LDS (XL: 630 channels)
 
 
 struct PwArgs {
@@ -288,6 +289,194 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Streaming variant with pre-packed weights (the default for stages 1-2): no LDS staging and no
+// barrier in the K loop.  Per group of 16 channels a wave issues MT coalesced 1-KiB loads of
+// packed weight fragments (L2-resident) and 4 activation loads (NT voxels x 4 channel rows
+// each, straight from HBM), then MT*4*NT MFMAs; the next group's loads are in flight meanwhile.
+// Channels >= K meet zero-padded weights and voxels >= P are never stored, so no load needs a
+// predicate -- addresses are only clamped into the tensor.
+// ---------------------------------------------------------------------------------------
+template <int MT, int NT, int IN, int EPI>
+__global__ __launch_bounds__(256) void pw3_kernel(const PwArgs A) {
+    __shared__ float red[4 * MT * 16 * 2];
+    __shared__ float Cl[(IN == IN_RAW) ? 4 : 3 * PW_MAXK];
+    constexpr int NC = (IN == IN_BNBWD) ? 3 : 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    const int n = blockIdx.y;
+    const int tlo = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int mb = rest % A.mblocks, tile = (rest / A.mblocks) * 8 + tlo;
+    if (tile >= A.tiles) return;
+    const int mt_run = A.mt_run;
+    const int m0 = mb * mt_run * 16;
+    const int bm = min(mt_run * 16, A.M - m0);
+    const int p0 = tile * (64 * NT) + wave * (16 * NT) + NT * r;
+    const int K = A.K, P = A.P;
+    const bool pv = p0 < P;
+    const int kgroups = (K + 15) / 16;
+
+    int off = pv ? p0 : 0;                       // clamped: always a valid voxel
+    if (NT == 1 && IN != IN_BNBWD && A.strided && pv) {
+        const int hw = A.Ho * A.Wo;
+        const int t = p0 / hw, rem = p0 - t * hw;
+        const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
+        off = (t * A.H + 2 * ho) * A.W + 2 * wo;
+    }
+    if (IN != IN_RAW) {
+        for (int i = tid; i < K * NC; i += 256) Cl[i] = A.cin[(size_t)n * K * NC + i];
+        __syncthreads();
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* xrow = A.x + (size_t)n * K * (size_t)A.Pin + off;
+    const float* arow = (IN == IN_BNBWD) ? A.a + (size_t)n * K * (size_t)P + off : nullptr;
+    const float* wpl[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        wpl[mt] = A.wp + ((size_t)min(mb * mt_run + mt, (A.M + 15) / 16 - 1) * kgroups) * 256 + lane * 4;   // clamped to a packed tile
+
+    float4 wa[MT], wn[MT];
+    float xb[4][NT], xn[4][NT], ab[(IN == IN_BNBWD) ? 4 : 1][NT], an_[(IN == IN_BNBWD) ? 4 : 1][NT];
+
+    auto issue = [&](int s, float4 (&wd)[MT], float (&xd)[4][NT], float (&ad)[(IN == IN_BNBWD) ? 4 : 1][NT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) wd[mt] = *reinterpret_cast<const float4*>(wpl[mt] + (size_t)s * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = min(16 * s + 4 * q + e, K - 1);
+            vload<NT>(xrow + (size_t)k * (size_t)A.Pin, xd[e]);
+            if (IN == IN_BNBWD) vload<NT>(arow + (size_t)k * (size_t)P, ad[e]);
+        }
+    };
+
+    auto compute = [&](int s, const float4 (&wd)[MT], const float (&xd)[4][NT],
+                       const float (&ad)[(IN == IN_BNBWD) ? 4 : 1][NT]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = min(16 * s + 4 * q + e, K - 1);
+            float b[NT];
+            if (IN == IN_BNBWD) {
+                const float c0 = Cl[k * 3], c1 = Cl[k * 3 + 1], c2 = Cl[k * 3 + 2];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = fmaf(c0, xd[e][j], fmaf(c1, ad[e][j], c2));
+            } else if (IN == IN_AFFACT) {
+                const float sc = Cl[k * 2], sh = Cl[k * 2 + 1];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = act_fwd(fmaf(sc, xd[e][j], sh), A.in_act);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = xd[e][j];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float av = e == 0 ? wd[mt].x : (e == 1 ? wd[mt].y : (e == 2 ? wd[mt].z : wd[mt].w));
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j], acc[mt][j], 0, 0, 0);
+            }
+        }
+    };
+
+    issue(0, wa, xb, ab);
+    for (int s = 0; s < kgroups; s += 2) {
+        if (s + 1 < kgroups) issue(s + 1, wn, xn, an_);
+        compute(s, wa, xb, ab);
+        if (s + 1 < kgroups) {
+            if (s + 2 < kgroups) issue(s + 2, wa, xb, ab);
+            compute(s + 1, wn, xn, an_);
+        }
+    }
+
+    // ------------------------------ epilogue ------------------------------
+    int aoff[NT];
+    if (EPI != EPI_STATS && A.addend != nullptr) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int p = p0 + j;
+            if (A.addend_stride == 2) {
+                const int hw = A.H * A.W;
+                const int t = p / hw, rem = p - t * hw;
+                const int h = rem / A.W, w = rem - h * A.W;
+                aoff[j] = (pv && !(h & 1) && !(w & 1)) ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : -1;
+            } else {
+                aoff[j] = pv ? p : -1;
+            }
+        }
+    }
+    const long long addP = (A.addend_stride == 2) ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (mt < mt_run) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = mt * 16 + 4 * q + e;
+                const int m = m0 + ml;
+                const bool mv = ml < bm;
+                float v[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) v[j] = acc[mt][j][e];
+                float s1 = 0.f, s2 = 0.f;
+                if (mv && pv) {
+                    float* py = A.y + ((size_t)n * A.M + m) * (size_t)P + p0;
+                    if (EPI != EPI_STATS && A.addend != nullptr) {
+                        const float* pa = A.addend + ((size_t)n * A.M + m) * (size_t)addP;
+                        if (A.addend_stride == 1 && NT == 4) {
+                            float t4[NT];
+                            vload<NT>(pa + p0, t4);
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) v[j] += t4[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) if (aoff[j] >= 0) v[j] += pa[aoff[j]];
+                        }
+                    }
+                    if (EPI == EPI_ACTBWD) {
+                        const float sc = A.ecoef[((size_t)n * A.M + m) * 2], sh = A.ecoef[((size_t)n * A.M + m) * 2 + 1];
+                        float xv[NT];
+                        vload<NT>(A.ex + ((size_t)n * A.M + m) * (size_t)P + p0, xv);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            v[j] = v[j] * act_bwd(fmaf(sc, xv[j], sh), A.e_act);
+                            s1 += v[j];
+                            s2 = fmaf(v[j], xv[j], s2);
+                        }
+                    } else if (EPI == EPI_STATS) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+                    }
+                    vstore<NT>(py, v);
+                }
+                if (EPI != EPI_PLAIN) {
+                    s1 = row16_sum(s1);
+                    s2 = row16_sum(s2);
+                    if (r == 0) {
+                        red[(wave * MT * 16 + ml) * 2] = s1;
+                        red[(wave * MT * 16 + ml) * 2 + 1] = s2;
+                    }
+                }
+            }
+        }
+    }
+    if (EPI != EPI_PLAIN && A.partial != nullptr) {
+        __syncthreads();
+        for (int idx = tid; idx < bm * 2; idx += 256) {
+            const int ml = idx >> 1, which = idx & 1;
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) s += red[(wv * MT * 16 + ml) * 2 + which];
+            A.partial[(((size_t)n * A.M + (m0 + ml)) * A.tiles + tile) * 2 + which] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Tiled variant for the large-C / small-P layers (stages 3-4, conv5): K >= 64, M >= 96.
 // Workgroup tile = up to 128 output channels x 64 voxels, K in chunks of 64 channels.
 //   * activations: staged ONCE per workgroup into a double-buffered LDS tile [64 ch][64 voxels]
@@ -301,7 +490,6 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
 // ---------------------------------------------------------------------------------------
 constexpr int P2_BN = 64, P2_KC = 64;
 constexpr int P2_NB = P2_KC * P2_BN / 4 / 256;      // activation float4 slots per thread
-constexpr int PW_MAXK = 640;   // per-sample input-coefficient table in LDS (XL: 630 channels)
 
 __global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, int K,
                                                       int ldm, int ldk, int mtiles, int kgroups) {
@@ -314,7 +502,7 @@ __global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ 
     wp[i] = (row < M && k < K) ? w[(size_t)row * ldm + (size_t)k * ldk] : 0.f;
 }
 
-template <int IN, int EPI, bool VEC>
+template <int IN, int EPI, bool VEC, bool TWO>
 __global__ __launch_bounds__(256) void pw2_kernel(const PwArgs A) {
     __shared__ __attribute__((aligned(16))) float Bl[2][P2_KC * P2_BN];
     __shared__ float Cl[(IN == IN_RAW) ? 4 : 3 * PW_MAXK];
@@ -423,9 +611,9 @@ __global__ __launch_bounds__(256) void pw2_kernel(const PwArgs A) {
 
     // this wave's M tiles: wave and wave + 4 (clamped to an existing tile: results of a clamped
     // duplicate are simply never stored)
-    const int lt0 = min(wave, mt_run - 1), lt1 = min(wave + 4, mt_run - 1);
-    const float* wp0 = A.wp + ((size_t)(mb * mt_run + lt0) * kgroups) * 256 + lane * 4;
-    const float* wp1 = A.wp + ((size_t)(mb * mt_run + lt1) * kgroups) * 256 + lane * 4;
+    const int mtl = (A.M + 15) / 16 - 1;           // last packed tile
+    const float* wp0 = A.wp + ((size_t)min(mb * mt_run + wave, mtl) * kgroups) * 256 + lane * 4;
+    const float* wp1 = A.wp + ((size_t)min(mb * mt_run + wave + 4, mtl) * kgroups) * 256 + lane * 4;
 
     f32x4 acc[2][4];
 #pragma unroll
@@ -433,21 +621,24 @@ __global__ __launch_bounds__(256) void pw2_kernel(const PwArgs A) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 a0[P2_KC / 16], a1[P2_KC / 16];
-    auto fetch_a = [&](int c) {
+    // weight fragments: two register sets, the next chunk's set is requested before the current
+    // chunk's MFMAs (L2 latency hidden under 128 MFMAs)
+    float4 a0[P2_KC / 16], a1[P2_KC / 16], b0[P2_KC / 16], b1[P2_KC / 16];
+    auto fetch_a = [&](int c, float4 (&d0)[P2_KC / 16], float4 (&d1)[P2_KC / 16]) {
 #pragma unroll
         for (int s4 = 0; s4 < P2_KC / 16; ++s4) {
             const int sg = min(c * (P2_KC / 16) + s4, kgroups - 1);     // clamped; extra groups meet zero B rows
-            a0[s4] = *reinterpret_cast<const float4*>(wp0 + (size_t)sg * 256);
-            a1[s4] = *reinterpret_cast<const float4*>(wp1 + (size_t)sg * 256);
+            d0[s4] = *reinterpret_cast<const float4*>(wp0 + (size_t)sg * 256);
+            if (TWO) d1[s4] = *reinterpret_cast<const float4*>(wp1 + (size_t)sg * 256);
+            else d1[s4] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, const float4 (&w0)[P2_KC / 16], const float4 (&w1)[P2_KC / 16]) {
 #pragma unroll
         for (int s4 = 0; s4 < P2_KC / 16; ++s4) {
-            const float av0[4] = {a0[s4].x, a0[s4].y, a0[s4].z, a0[s4].w};
-            const float av1[4] = {a1[s4].x, a1[s4].y, a1[s4].z, a1[s4].w};
+            const float av0[4] = {w0[s4].x, w0[s4].y, w0[s4].z, w0[s4].w};
+            const float av1[4] = {w1[s4].x, w1[s4].y, w1[s4].z, w1[s4].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float4 b = *reinterpret_cast<const float4*>(&Bl[buf][(s4 * 16 + 4 * q + e) * P2_BN + 4 * r]);
@@ -455,10 +646,12 @@ __global__ __launch_bounds__(256) void pw2_kernel(const PwArgs A) {
                 acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], b.y, acc[0][1], 0, 0, 0);
                 acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], b.z, acc[0][2], 0, 0, 0);
                 acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], b.w, acc[0][3], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.y, acc[1][1], 0, 0, 0);
-                acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.z, acc[1][2], 0, 0, 0);
-                acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.w, acc[1][3], 0, 0, 0);
+                if (TWO) {      // M blocks of more than 4 tiles: second tile of this wave
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.x, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.y, acc[1][1], 0, 0, 0);
+                    acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.z, acc[1][2], 0, 0, 0);
+                    acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], b.w, acc[1][3], 0, 0, 0);
+                }
             }
         }
     };
@@ -466,14 +659,20 @@ __global__ __launch_bounds__(256) void pw2_kernel(const PwArgs A) {
     const int nchunks = (K + P2_KC - 1) / P2_KC;
     __syncthreads();            // Cl visible
     fetch(0);
-    fetch_a(0);
+    fetch_a(0, a0, a1);
     store(0, 0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) fetch(c + 1);
-        compute(c & 1);
-        if (c + 1 < nchunks) { fetch_a(c + 1); store(c + 1, (c + 1) & 1); }
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 1 < nchunks) { fetch(c + 1); fetch_a(c + 1, b0, b1); }
+        compute(0, a0, a1);
+        if (c + 1 < nchunks) store(c + 1, 1);
         __syncthreads();
+        if (c + 1 < nchunks) {
+            if (c + 2 < nchunks) { fetch(c + 2); fetch_a(c + 2, a0, a1); }
+            compute(1, b0, b1);
+            if (c + 2 < nchunks) store(c + 2, 0);
+            __syncthreads();
+        }
     }
 
     // ------------------------------ epilogue ------------------------------
@@ -562,7 +761,13 @@ static void pw_plan(int N, int K, int M, int P, bool dense, int* variant, int* t
     const int mtiles = cdiv(M, 16);
     if (K >= 64 && M >= 96) {
         *variant = 2;
-        *mblocks = cdiv(mtiles, 8);
+        // waves own tiles {w, w+4}: a block of 5..8 tiles costs two tile-times, 1..4 tiles one;
+        // pick the blocking with the smaller (blocks x tile-times); ties -> fewer blocks (the
+        // activation tile is staged once per block)
+        const int b8 = cdiv(mtiles, 8), b4 = cdiv(mtiles, 4);
+        const int r8 = cdiv(mtiles, b8);
+        const int cost8 = b8 * (r8 > 4 ? 2 : 1), cost4 = b4;
+        *mblocks = (cost4 < cost8) ? b4 : b8;
         *mt_run = cdiv(mtiles, *mblocks);
         *tiles = cdiv(P, P2_BN);
         return;
@@ -593,8 +798,22 @@ int launch_pw(PwArgs& A, hipStream_t s) {
     }
     if (variant == 2) {
         if (A.K > PW_MAXK) { x3d_set_error("pw: K=%d exceeds the coefficient table (%d)", A.K, PW_MAXK); return X3D_EINVAL; }
-        if (dense && (A.P % 4 == 0)) hipLaunchKernelGGL((pw2_kernel<IN, EPI, true>), grid, block, 0, s, A);
-        else hipLaunchKernelGGL((pw2_kernel<IN, EPI, false>), grid, block, 0, s, A);
+        const bool vec = dense && (A.P % 4 == 0);
+        if (A.mt_run > 4) {
+            if (vec) hipLaunchKernelGGL((pw2_kernel<IN, EPI, true, true>), grid, block, 0, s, A);
+            else hipLaunchKernelGGL((pw2_kernel<IN, EPI, false, true>), grid, block, 0, s, A);
+        } else {
+            if (vec) hipLaunchKernelGGL((pw2_kernel<IN, EPI, true, false>), grid, block, 0, s, A);
+            else hipLaunchKernelGGL((pw2_kernel<IN, EPI, false, false>), grid, block, 0, s, A);
+        }
+    } else if (A.wp != nullptr && A.K <= PW_MAXK) {
+        if (A.mt_run <= 2) {
+            if (variant == 0) hipLaunchKernelGGL((pw3_kernel<2, 4, IN, EPI>), grid, block, 0, s, A);
+            else hipLaunchKernelGGL((pw3_kernel<2, 1, IN, EPI>), grid, block, 0, s, A);
+        } else {
+            if (variant == 0) hipLaunchKernelGGL((pw3_kernel<4, 4, IN, EPI>), grid, block, 0, s, A);
+            else hipLaunchKernelGGL((pw3_kernel<4, 1, IN, EPI>), grid, block, 0, s, A);
+        }
     } else if (A.mt_run <= 2) {
         if (variant == 0) hipLaunchKernelGGL((pw_kernel<2, 4, IN, EPI>), grid, block, 0, s, A);
         else hipLaunchKernelGGL((pw_kernel<2, 1, IN, EPI>), grid, block, 0, s, A);
@@ -841,7 +1060,7 @@ extern "C" int x3d_pw_tiles(int N, int K, int M, int P, int dense) {
     return tiles;
 }
 
-extern "C" int x3d_pw_wants_packed(int K, int M) { return (K >= 64 && M >= 96) ? 1 : 0; }
+extern "C" int x3d_pw_wants_packed(int K, int M) { (void)K; (void)M; return 1; }
 
 extern "C" size_t x3d_pw_pack_floats(int K, int M) { return (size_t)cdiv(M, 16) * cdiv(K, 16) * 256; }
 
