@@ -173,12 +173,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # test hook (tests/test_bench_ddp_gpu.py): several ranks on ONE GPU over gloo, to exercise the
+    # multi-rank control flow on a single-GPU box; the real launch is one rank per GPU over RCCL
+    single_dev = os.environ.get("X3D_BENCH_SINGLE_DEVICE") == "1"
+    backend = os.environ.get("X3D_BENCH_BACKEND", "nccl")
+    if single_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     import x3d
