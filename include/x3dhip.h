@@ -95,7 +95,7 @@ int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float
 /* Backward-weight: dW[co,ci] = sum_{n,p} dY[co,p] * in[ci,p] with dY and in formed as above
  * (strideHW 2: in is sampled at even (h,w) of x[N,Cin,T,H,W]; g,a are at output resolution).
  * wpartial is float[x3d_pw_wgrad_groups(...)][Cout][Cin]; x3d_reduce_partials sums it. */
-int x3d_pw_wgrad_groups(int N, int P, int Cout, int Cin);
+int x3d_pw_wgrad_groups(int N, int P, int Cout, int Cin, int strideHW);
 int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb,
                       const float* x, const float* pre, int pre_act,
                       float* wpartial, int N, int Cin, int Cout, int T, int H, int W,

@@ -1018,7 +1018,166 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs A) {
     }
 }
 
-static void wgrad_plan(int N, int P, int Co, int Ci, int* groups, int* cob, int* cib, int* ct_run, int* it_run) {
+// ---------------------------------------------------------------------------------------
+// Tiled backward-weight for the large-C layers (Co >= 64 and Ci >= 48, dense, P % 4 == 0).
+// Workgroup = one (128 co x 64 ci) block of dW and a strided set of 64-voxel chunks.  Per chunk
+// dY[128][64] (= cb0*g + cb1*a + cb2) and in[64][64] (prologue applied) are staged ONCE into
+// LDS ([rows][68]); the four waves own 2 co-tiles x 4 ci-tiles each (32 accumulator registers)
+// and read fragments with ds_read_b128 (voxel index on the MFMA K dimension, permuted
+// identically on both operands).  Loads for chunk c+1 are in flight during the MFMAs of chunk c
+// (registers), every load is unconditional from a clamped address.
+// ---------------------------------------------------------------------------------------
+constexpr int W2_CO = 128, W2_CI = 64, W2_PT = 64, W2_LD = 68;
+constexpr int W2_ND = W2_CO * W2_PT / 4 / 256;     // dY float4 slots per thread (8)
+constexpr int W2_NX = W2_CI * W2_PT / 4 / 256;     // in float4 slots per thread (4)
+
+__global__ __launch_bounds__(256) void pw_wgrad2_kernel(const WgArgs A) {
+    __shared__ __attribute__((aligned(16))) float Dl[W2_CO * W2_LD];
+    __shared__ __attribute__((aligned(16))) float Xl[W2_CI * W2_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int blk = blockIdx.y;
+    const int co0 = (blk / A.cib) * W2_CO, ci0 = (blk % A.cib) * W2_CI;
+    const int P = A.P;
+    const int cps = (P + W2_PT - 1) / W2_PT;            // chunks per sample
+    const int total = A.N * cps;
+
+    // staging slots: row-major, 16 lanes x 16 B = 256 B contiguous per row
+    const int c4 = (tid & 15) * 4;
+    int drow[W2_ND], xrow_[W2_NX];
+#pragma unroll
+    for (int i = 0; i < W2_ND; ++i) drow[i] = i * 16 + (tid >> 4);
+#pragma unroll
+    for (int i = 0; i < W2_NX; ++i) xrow_[i] = i * 16 + (tid >> 4);
+
+    float4 rg[W2_ND], ra[W2_ND], rx[W2_NX];
+    float k0[W2_ND], k1[W2_ND], k2[W2_ND], sc[W2_NX], sh[W2_NX];
+#pragma unroll
+    for (int i = 0; i < W2_NX; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+
+    auto fetch = [&](int c) {
+        const int n = c / cps, pt = (c - n * cps) * W2_PT;
+        const int pc = min(pt + c4, P - 4);
+#pragma unroll
+        for (int i = 0; i < W2_ND; ++i) {
+            const int co = min(co0 + drow[i], A.Co - 1);
+            const size_t base = ((size_t)n * A.Co + co) * (size_t)P + pc;
+            rg[i] = *reinterpret_cast<const float4*>(A.g + base);
+            ra[i] = *reinterpret_cast<const float4*>(A.a + base);
+            const float* cb = A.cb + ((size_t)n * A.Co + co) * 3;
+            k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
+        }
+#pragma unroll
+        for (int i = 0; i < W2_NX; ++i) {
+            const int ci = min(ci0 + xrow_[i], A.Ci - 1);
+            rx[i] = *reinterpret_cast<const float4*>(A.x + ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc);
+            if (A.pre != nullptr) { sc[i] = A.pre[((size_t)n * A.Ci + ci) * 2]; sh[i] = A.pre[((size_t)n * A.Ci + ci) * 2 + 1]; }
+        }
+    };
+    auto store = [&](int c) {
+        const int n = c / cps, pt = (c - n * cps) * W2_PT;
+        const bool pvv = pt + c4 < P;                   // P % 4 == 0: all four or none
+#pragma unroll
+        for (int i = 0; i < W2_ND; ++i) {
+            const bool ok = pvv && (co0 + drow[i] < A.Co);
+            float4 v;
+            v.x = ok ? fmaf(k0[i], rg[i].x, fmaf(k1[i], ra[i].x, k2[i])) : 0.f;
+            v.y = ok ? fmaf(k0[i], rg[i].y, fmaf(k1[i], ra[i].y, k2[i])) : 0.f;
+            v.z = ok ? fmaf(k0[i], rg[i].z, fmaf(k1[i], ra[i].z, k2[i])) : 0.f;
+            v.w = ok ? fmaf(k0[i], rg[i].w, fmaf(k1[i], ra[i].w, k2[i])) : 0.f;
+            *reinterpret_cast<float4*>(&Dl[drow[i] * W2_LD + c4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < W2_NX; ++i) {
+            const bool ok = pvv && (ci0 + xrow_[i] < A.Ci);
+            float4 v = rx[i];
+            if (A.pre != nullptr) {
+                v.x = act_fwd(fmaf(sc[i], v.x, sh[i]), A.pre_act);
+                v.y = act_fwd(fmaf(sc[i], v.y, sh[i]), A.pre_act);
+                v.z = act_fwd(fmaf(sc[i], v.z, sh[i]), A.pre_act);
+                v.w = act_fwd(fmaf(sc[i], v.w, sh[i]), A.pre_act);
+            }
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            *reinterpret_cast<float4*>(&Xl[xrow_[i] * W2_LD + c4]) = v;
+        }
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&]() {
+#pragma unroll
+        for (int s4 = 0; s4 < W2_PT / 16; ++s4) {
+            float4 av[2], bv[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                av[i] = *reinterpret_cast<const float4*>(&Dl[((2 * wave + i) * 16 + r) * W2_LD + s4 * 16 + 4 * q]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bv[j] = *reinterpret_cast<const float4*>(&Xl[(j * 16 + r) * W2_LD + s4 * 16 + 4 * q]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    int c = blockIdx.x;
+    if (c < total) {
+        fetch(c);
+        store(c);
+        __syncthreads();
+        for (; c < total; c += A.groups) {
+            const int cn = c + A.groups;
+            if (cn < total) fetch(cn);
+            compute();
+            __syncthreads();                 // everyone done reading this chunk
+            if (cn < total) { store(cn); __syncthreads(); }
+        }
+    }
+
+    // D[i = co][j = ci]: lane (q, r), reg e -> co = tile*16 + 4q + e, ci = tile*16 + r
+    float* out = A.wpartial + (size_t)blockIdx.x * A.Co * A.Ci;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int oc = co0 + (2 * wave + i) * 16 + 4 * q + e, ic = ci0 + j * 16 + r;
+                if (oc < A.Co && ic < A.Ci) out[(size_t)oc * A.Ci + ic] = acc[i][j][e];
+            }
+}
+
+static bool wgrad2_ok(int P, long long Pin, int Co, int Ci, bool strided) {
+    return !strided && (P % 4 == 0) && (Pin % 4 == 0) && Co >= 64 && Ci >= 48;
+}
+
+// tiled = 1: pw_wgrad2_kernel (cob x cib blocks of 128 x 64), else the direct-load kernel
+static void wgrad_plan(int N, int P, int Co, int Ci, bool dense, int* tiled, int* groups, int* cob, int* cib,
+                       int* ct_run, int* it_run) {
+    if (wgrad2_ok(P, dense ? P : 1, Co, Ci, !dense)) {
+        *tiled = 1;
+        *cob = cdiv(Co, W2_CO); *cib = cdiv(Ci, W2_CI);
+        *ct_run = 8; *it_run = 4;
+        const int chunks = N * cdiv(P, W2_PT);
+        int g = cdiv(chunks, 6);                                   // ~6 chunks per workgroup ...
+        const int cap = 640 / ((*cob) * (*cib)) > 16 ? 640 / ((*cob) * (*cib)) : 16;   // ... but <= ~640 workgroups
+        if (g > cap) g = cap;
+        if (g < 1) g = 1;
+        *groups = g;
+        return;
+    }
+    *tiled = 0;
     const int cot = cdiv(Co, 16), cit = cdiv(Ci, 16);
     *cob = cdiv(cot, 4); *cib = cdiv(cit, 4);
     *ct_run = cdiv(cot, *cob); *it_run = cdiv(cit, *cib);
@@ -1116,9 +1275,9 @@ extern "C" int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, 
     return launch_pw<IN_BNBWD, EPI_PLAIN>(A, s);
 }
 
-extern "C" int x3d_pw_wgrad_groups(int N, int P, int Cout, int Cin) {
-    int g, cob, cib, ct, it;
-    wgrad_plan(N, P, Cout, Cin, &g, &cob, &cib, &ct, &it);
+extern "C" int x3d_pw_wgrad_groups(int N, int P, int Cout, int Cin, int strideHW) {
+    int tiled, g, cob, cib, ct, it;
+    wgrad_plan(N, P, Cout, Cin, strideHW == 1, &tiled, &g, &cob, &cib, &ct, &it);
     return g;
 }
 
@@ -1134,9 +1293,16 @@ extern "C" int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb
     A.N = N; A.Ci = Cin; A.Co = Cout; A.P = T * Ho * Wo; A.Pin = (long long)T * H * W;
     A.strided = strideHW == 2; A.T = T; A.H = H; A.W = W; A.Ho = Ho; A.Wo = Wo;
     A.units_per_sample = cdiv(A.P, WG_UNIT);
-    wgrad_plan(N, A.P, Cout, Cin, &A.groups, &A.cob, &A.cib, &A.ct_run, &A.it_run);
+    int tiled;
+    wgrad_plan(N, A.P, Cout, Cin, strideHW == 1 && (A.Pin % 4 == 0), &tiled, &A.groups, &A.cob, &A.cib, &A.ct_run,
+               &A.it_run);
     X3D_CHECK_ARG(A.cob * A.cib <= 65535);
     dim3 grid(A.groups, A.cob * A.cib), block(256);
+    if (tiled) {
+        hipLaunchKernelGGL(pw_wgrad2_kernel, grid, block, 0, (hipStream_t)stream, A);
+        X3D_LAUNCH_CHECK();
+        return X3D_OK;
+    }
     const bool vec = (A.P % 4 == 0) && !A.strided && (A.Pin % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
 #define WG_LAUNCH(CT_, IT_)                                                                         \

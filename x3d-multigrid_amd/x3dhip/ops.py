@@ -101,7 +101,7 @@ def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, ou
     N, Cin, T, H, W = x.shape
     Cout = g.shape[1]
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
-    groups = L.x3d_pw_wgrad_groups(N, T * Ho * Wo, Cout, Cin)
+    groups = L.x3d_pw_wgrad_groups(N, T * Ho * Wo, Cout, Cin, stride)
     if wpartial is None:
         wpartial = _f((groups, Cout, Cin), g)
     check(L.x3d_pw_bwd_weight(ptr(g), ptr(a), ptr(cb), ptr(x), ptr(pre), pre_act, ptr(wpartial), N, Cin, Cout, T,
