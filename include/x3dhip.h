@@ -68,6 +68,12 @@ int x3d_pw_tiles(int N, int K, int M, int P, int dense);
 int x3d_pw_wants_packed(int K, int M);
 size_t x3d_pw_pack_floats(int K, int M);
 int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int transposed, void* stream);
+/* Batched packing: `jobs` is a device array of records
+ *   { const float* w; float* wp; int M, K, ldm, ldk, mtiles, kgroups, wg0, pad; }   (x3d_pw_pack_job_bytes() each;
+ *   A[row][k] = w[row*ldm + k*ldk], mtiles = ceil(M/16), kgroups = ceil(K/16), wg0 = first workgroup of the job)
+ * and wg_job[n_workgroups] maps every 256-element workgroup to its job. */
+size_t x3d_pw_pack_job_bytes(void);
+int x3d_pw_pack_batch(const void* jobs, const int* wg_job, int n_workgroups, void* stream);
 
 int x3d_pw_fwd(const float* x, const float* w, const float* wpacked, float* y,
                int N, int Cin, int Cout, int T, int H, int W, int strideHW,

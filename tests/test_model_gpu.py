@@ -113,7 +113,9 @@ def test_blocks_tight_vs_oracle(shape):
         dout = torch.randn(out_ref.shape, generator=g, dtype=torch.float64)
         out_ref.backward(dout)
         ctx = engine.TrunkContext()
-        out, _ = engine._block_forward(blk, x.float().to(dev), None, S, True, ctx)
+        packs = engine.weight_packs(net)
+        packs.refresh()
+        out, _ = engine._block_forward(blk, x.float().to(dev), None, S, True, ctx, packs)
         assert parity.rel(out.cpu().numpy(), out_ref.detach().numpy()) < 2e-5, name
         sink = engine._GradSink(False)
         dprev, _ = engine._block_backward(ctx.blocks[0], dout.float().to(dev), sink)

@@ -68,7 +68,7 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[NT]) {
 }
 
 template <int MT, int NT, int IN, int EPI>
-__global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
+__global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs A) {
     constexpr int PW_KC = 32;     // channels per LDS weight chunk
     constexpr int PW_KPAD = 34;   // LDS row stride of the weight chunk (conflict-free fragment reads)
     __shared__ float Wl[MT * 16 * PW_KPAD];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const PwArgs A) {
 // predicate -- addresses are only clamped into the tensor.
 // ---------------------------------------------------------------------------------------
 template <int MT, int NT, int IN, int EPI>
-__global__ __launch_bounds__(256) void pw3_kernel(const PwArgs A) {
+__global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
     __shared__ float red[4 * MT * 16 * 2];
     __shared__ float Cl[(IN == IN_RAW) ? 4 : 3 * PW_MAXK];
     constexpr int NC = (IN == IN_BNBWD) ? 3 : 2;
@@ -502,8 +502,26 @@ __global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ 
     wp[i] = (row < M && k < K) ? w[(size_t)row * ldm + (size_t)k * ldk] : 0.f;
 }
 
+// Batched form: one launch packs every pointwise weight of the network in both orientations.
+// jobs[] and the workgroup -> job table are built once on the host (x3dhip/engine.py).
+struct PackJob {
+    const float* w; float* wp;
+    int M, K, ldm, ldk, mtiles, kgroups, wg0, pad;
+};
+
+__global__ __launch_bounds__(256) void pw_pack_batch_kernel(const PackJob* __restrict__ jobs,
+                                                            const int* __restrict__ wg_job) {
+    const PackJob J = jobs[wg_job[blockIdx.x]];
+    const int i = (blockIdx.x - J.wg0) * 256 + threadIdx.x;
+    if (i >= J.mtiles * J.kgroups * 256) return;
+    const int e = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+    const int s = blk % J.kgroups, mt = blk / J.kgroups;
+    const int row = 16 * mt + (lane & 15), k = 16 * s + 4 * (lane >> 4) + e;
+    J.wp[i] = (row < J.M && k < J.K) ? J.w[(size_t)row * J.ldm + (size_t)k * J.ldk] : 0.f;
+}
+
 template <int IN, int EPI, bool VEC, bool TWO>
-__global__ __launch_bounds__(256) void pw2_kernel(const PwArgs A) {
+__global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
     __shared__ __attribute__((aligned(16))) float Bl[2][P2_KC * P2_BN];
     __shared__ float Cl[(IN == IN_RAW) ? 4 : 3 * PW_MAXK];
     constexpr int NC = (IN == IN_BNBWD) ? 3 : 2;
@@ -848,7 +866,7 @@ struct WgArgs {
 };
 
 template <int CT, int IT, bool VEC>
-__global__ __launch_bounds__(256) void pw_wgrad_kernel(const WgArgs A) {
+__global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs A) {
     __shared__ float red[4 * IT * 4 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
@@ -1031,7 +1049,7 @@ constexpr int W2_CO = 128, W2_CI = 64, W2_PT = 64, W2_LD = 68;
 constexpr int W2_ND = W2_CO * W2_PT / 4 / 256;     // dY float4 slots per thread (8)
 constexpr int W2_NX = W2_CI * W2_PT / 4 / 256;     // in float4 slots per thread (4)
 
-__global__ __launch_bounds__(256) void pw_wgrad2_kernel(const WgArgs A) {
+__global__ __launch_bounds__(256, 2) void pw_wgrad2_kernel(const WgArgs A) {
     __shared__ __attribute__((aligned(16))) float Dl[W2_CO * W2_LD];
     __shared__ __attribute__((aligned(16))) float Xl[W2_CI * W2_LD];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1232,6 +1250,16 @@ extern "C" int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int tra
     const int mtiles = cdiv(M, 16), kgroups = cdiv(K, 16);
     hipLaunchKernelGGL(pw_pack_kernel, dim3(cdiv(mtiles * kgroups * 256, 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
                        M, K, ldm, ldk, mtiles, kgroups);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" size_t x3d_pw_pack_job_bytes(void) { return sizeof(PackJob); }
+
+extern "C" int x3d_pw_pack_batch(const void* jobs, const int* wg_job, int n_workgroups, void* stream) {
+    X3D_CHECK_ARG(jobs && wg_job && n_workgroups > 0);
+    hipLaunchKernelGGL(pw_pack_batch_kernel, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream,
+                       (const PackJob*)jobs, wg_job);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

@@ -28,6 +28,8 @@ SIGNATURES = {
     "x3d_pw_wants_packed": (_I, [_I, _I]),
     "x3d_pw_pack_floats": (_Z, [_I, _I]),
     "x3d_pw_pack": (_I, [_P, _P, _I, _I, _I, _P]),
+    "x3d_pw_pack_job_bytes": (_Z, []),
+    "x3d_pw_pack_batch": (_I, [_P, _P, _I, _P]),
     "x3d_pw_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "x3d_pw_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P]),
     "x3d_pw_wgrad_groups": (_I, [_I, _I, _I, _I, _I]),

@@ -45,6 +45,70 @@ def _w2d(p):
     return p.data.view(p.shape[0], -1)
 
 
+class WeightPacks:
+    """All pointwise weights of a model pre-packed into MFMA fragment order (forward and
+    backward-data orientation), refreshed with ONE kernel launch per forward pass."""
+
+    def __init__(self, model):
+        import numpy as np
+        from . import _lib
+        L = _lib.lib()
+        convs = []
+        for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
+            for blk in layer:
+                convs += [blk.conv1.weight, blk.conv3.weight]
+                if blk.downsample is not None:
+                    convs.append(blk.downsample[0].weight)
+        convs.append(model.conv5.weight)
+        dev = convs[0].device
+        assert L.x3d_pw_pack_job_bytes() == 48
+        dt = np.dtype([("w", "<u8"), ("wp", "<u8"), ("M", "<i4"), ("K", "<i4"), ("ldm", "<i4"), ("ldk", "<i4"),
+                       ("mtiles", "<i4"), ("kgroups", "<i4"), ("wg0", "<i4"), ("pad", "<i4")])
+        sizes, metas = [], []
+        for w in convs:
+            co, ci = w.shape[0], w.shape[1]
+            for transposed in (False, True):
+                M, K = (ci, co) if transposed else (co, ci)
+                n = int(L.x3d_pw_pack_floats(K, M))
+                sizes.append(n)
+                metas.append((w, transposed, M, K, 1 if transposed else ci, ci if transposed else 1))
+        self.buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        jobs = np.zeros(len(metas), dtype=dt)
+        wg_job, off, wg = [], 0, 0
+        self.views, self.ptrs = {}, []
+        for j, ((w, transposed, M, K, ldm, ldk), n) in enumerate(zip(metas, sizes)):
+            view = self.buf[off:off + n]
+            self.views[(id(w), transposed)] = view
+            nwg = (n + 255) // 256
+            jobs[j] = (w.data_ptr(), view.data_ptr(), M, K, ldm, ldk, (M + 15) // 16, (K + 15) // 16, wg, 0)
+            wg_job += [j] * nwg
+            self.ptrs.append(w.data_ptr())
+            off += n
+            wg += nwg
+        self.nwg = wg
+        self.jobs = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
+        self.wg_job = torch.tensor(wg_job, dtype=torch.int32, device=dev)
+        self.params = convs
+
+    def stale(self):
+        return any(w.data_ptr() != p for w, p in zip(self.params, self.ptrs[::2]))
+
+    def refresh(self):
+        from . import _lib
+        _lib.check(_lib.lib().x3d_pw_pack_batch(self.jobs.data_ptr(), self.wg_job.data_ptr(), self.nwg, _lib.stream()))
+
+    def get(self, w, transposed=False):
+        return self.views[(id(w), transposed)]
+
+
+def weight_packs(model):
+    wp = getattr(model, "_x3d_weight_packs", None)
+    if wp is None or wp.stale():
+        wp = WeightPacks(model)
+        model._x3d_weight_packs = wp
+    return wp
+
+
 class TrunkContext:
     """Everything the backward pass needs from one forward pass."""
 
@@ -69,6 +133,8 @@ def trunk_forward(model, x, training, ctx=None):
     the head's fc1, x3d.py:331-333).  ctx (TrunkContext) collects what backward needs."""
     N, _, T, H, W = x.shape
     S = model.bn1.num_splits
+    packs = weight_packs(model)
+    packs.refresh()                      # weights changed since the last step: one launch re-packs all
     if training and N % S != 0:
         raise ValueError("batch size %d is not divisible by num_splits %d (x3d.py:50)" % (N, S))
 
@@ -86,11 +152,11 @@ def trunk_forward(model, x, training, ctx=None):
     cur_raw, cur_coef = a_t, c0          # lazy: consumers apply relu(c0 * a_t)
     for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
         for blk in layer:
-            cur_raw, cur_coef = _block_forward(blk, cur_raw, cur_coef, S, training, ctx)
+            cur_raw, cur_coef = _block_forward(blk, cur_raw, cur_coef, S, training, ctx, packs)
 
     # ---- conv5 / bn5 / relu / global average pool
     w5 = _w2d(model.conv5.weight)
-    a5, p5 = ops.pw_fwd(cur_raw, w5, want_stats=training, wp=ops.pw_pack(w5))
+    a5, p5 = ops.pw_fwd(cur_raw, w5, want_stats=training, wp=packs.get(model.conv5.weight))
     P5 = a5[0, 0].numel()
     if training:
         c5, save5, _ = _bn_train(p5, model.bn5, S, P5)
@@ -98,16 +164,16 @@ def trunk_forward(model, x, training, ctx=None):
         c5, save5 = _bn_eval(model.bn5, N), None
     pooled = ops.bn_relu_pool_fwd(a5, c5)
     if ctx is not None:
-        ctx.head = dict(x4=cur_raw, a5=a5, c5=c5, save5=save5, S=S, w5t=ops.pw_pack(w5, transposed=True))
+        ctx.head = dict(x4=cur_raw, a5=a5, c5=c5, save5=save5, S=S, w5t=packs.get(model.conv5.weight, True))
     return pooled
 
 
-def _block_forward(blk, x_raw, x_coef, S, training, ctx):
+def _block_forward(blk, x_raw, x_coef, S, training, ctx, packs):
     N = x_raw.shape[0]
     pre_act = ACT_RELU if x_coef is not None else ACT_NONE
     stride = blk.stride
     w1, w3 = _w2d(blk.conv1.weight), _w2d(blk.conv3.weight)
-    a1, p1 = ops.pw_fwd(x_raw, w1, pre=x_coef, pre_act=pre_act, want_stats=training, wp=ops.pw_pack(w1))
+    a1, p1 = ops.pw_fwd(x_raw, w1, pre=x_coef, pre_act=pre_act, want_stats=training, wp=packs.get(blk.conv1.weight))
     P1 = a1[0, 0].numel()
     if training:
         c1, s1, _ = _bn_train(p1, blk.bn1, S, P1)
@@ -130,7 +196,7 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx):
         se = dict(se=se_v, z=z, pool=pool, nsum=nsum2)
     else:
         c2e = c2
-    a3, p3 = ops.pw_fwd(a2, w3, pre=c2e, pre_act=ACT_SWISH, want_stats=training, wp=ops.pw_pack(w3))
+    a3, p3 = ops.pw_fwd(a2, w3, pre=c2e, pre_act=ACT_SWISH, want_stats=training, wp=packs.get(blk.conv3.weight))
     if training:
         c3, s3, _ = _bn_train(p3, blk.bn3, S, P2)
     else:
@@ -139,7 +205,7 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx):
     if blk.downsample is not None:
         wd = _w2d(blk.downsample[0].weight)
         ad, pd = ops.pw_fwd(x_raw, wd, stride=stride, pre=x_coef, pre_act=pre_act, want_stats=training,
-                            wp=ops.pw_pack(wd))
+                            wp=packs.get(blk.downsample[0].weight))
         if training:
             cd, sd, _ = _bn_train(pd, blk.downsample[1], S, P2)
         else:
@@ -153,8 +219,8 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx):
         # transposed packs for the backward-data GEMMs (weights are unchanged until the optimizer step)
         ctx.blocks.append(dict(blk=blk, x_raw=x_raw, x_coef=x_coef, a1=a1, c1=c1, s1=s1, a2=a2, c2e=c2e, s2=s2,
                                se=se, a3=a3, s3=s3, ad=ad, sd=sd, out=out, S=S,
-                               w1t=ops.pw_pack(w1, transposed=True), w3t=ops.pw_pack(w3, transposed=True),
-                               wdt=ops.pw_pack(_w2d(blk.downsample[0].weight), transposed=True)
+                               w1t=packs.get(blk.conv1.weight, True), w3t=packs.get(blk.conv3.weight, True),
+                               wdt=packs.get(blk.downsample[0].weight, True)
                                if blk.downsample is not None else None))
     return out, None
 
