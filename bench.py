@@ -132,25 +132,34 @@ def _alg_bytes(name, a, k, r):
     return 0
 
 
-def cpu_baseline(T, H, sample_B=2, steps=2):
+def cpu_baseline(T, H, sample_B=2, budget_s=12.0, min_steps=3, max_steps=12):
     """CPU oracle (port of the reference) on the host cores: fwd+bwd on a B=2 sample."""
     from oracle import x3d_oracle as xo
     from x3dhip import synthetic
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core CPU share (os.cpu_count() reports the whole host):
+    # use the affinity mask, capped at 16 threads
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
+    print("[bench] cpu baseline: oracle fwd+bwd on %d threads ..." % cores, file=sys.stderr, flush=True)
     sd = synthetic.procedural_state_dict(xo.state_template("M", 400, 1), 0)
     x = synthetic.synthetic_clips(sample_B, T, H, H)
     y = synthetic.synthetic_labels(sample_B)
     xo.train_step_grads(x, y, sd, "M", 1)         # warm-up
     ts = []
-    for _ in range(steps):
+    t_begin = time.time()
+    while len(ts) < min_steps or (time.time() - t_begin < budget_s and len(ts) < max_steps):
         t0 = time.time()
         xo.train_step_grads(x, y, sd, "M", 1)
         ts.append(time.time() - t0)
+        print("[bench] cpu baseline step %.2f s" % ts[-1], file=sys.stderr, flush=True)
     t = sorted(ts)[len(ts) // 2]
     return {"value": round(sample_B / t, 3), "unit": "clips/s", "cores": cores, "kind": "port",
             "sample": "oracle/x3d_oracle.py fwd+bwd, X3D-M B=%d T=%d H=W=%d fp32, median of %d steps, torch CPU %d threads"
-                      % (sample_B, T, H, steps, cores)}
+                      % (sample_B, T, H, len(ts), cores)}
 
 
 def main():
@@ -243,6 +252,7 @@ def main():
         # one instrumented eager step: HIP events around every launch, same tensors
         tr_e = tr
         tr_e.use_graph = False
+        os.environ["X3D_NO_SIDE_STREAM"] = "1"      # serialise the weight-gradient kernels: clean per-kernel times
         for _ in range(2):          # eager warm-up: allocator + code objects outside the graph pool
             tr_e.step(x, y)
         torch.cuda.synchronize()
@@ -256,9 +266,16 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         name, (tms, nbytes, cnt) = dom
         ach = nbytes / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written by tools/collect_traffic.py from PMC passes
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": name, "launches_per_step": cnt,
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "avg_launch_ms": round(tms / cnt, 4),
                            "alg_bytes_per_launch": int(nbytes / cnt),
                            "share_of_step_device_time": round(tms / tot, 3)}

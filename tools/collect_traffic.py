@@ -1,0 +1,63 @@
+"""Turn rocprofv3 PMC passes (FETCH_SIZE pass + WRITE_SIZE pass, each with --kernel-trace only) of
+`python3 bench.py --no-graph ...` into per-launch HBM traffic per kernel family, applying the gfx950
+correction from /opt/skills/guides/MI355X_MICROARCH.md (section HBM): FETCH_SIZE under-reports wide coalesced
+reads by exactly 2x; both counters are in KiB.
+
+    python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json>
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+FAMILY = [("pw_wgrad", "pw_bwd_weight"), ("pw2_kernel", "pw"), ("pw3_kernel", "pw"), ("pw_kernel", "pw"),
+          ("dw_fwd_kernel", "dw333_fwd"), ("dw_bwd_kernel", "dw333_bwd"), ("bn_add_relu_fwd", "bn_add_relu_fwd"),
+          ("bn_add_relu_bwd", "bn_add_relu_bwd"), ("dw5t_fwd", "dw5t_fwd"), ("dw5t_bwd", "dw5t_bwd"),
+          ("stem133_fwd", "stem133_fwd"), ("stem133_wgrad", "stem133_bwd_weight")]
+
+
+def load(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+def fam(name):
+    for key, f in FAMILY:
+        if key in name:
+            return f
+    return None
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for k, vals in fetch.items():
+        f = fam(k)
+        if f:
+            agg[f][0] += 2.0 * 1024.0 * sum(vals)          # x2: gfx950 FETCH_SIZE correction, KiB -> B
+            agg[f][2] += len(vals)
+    for k, vals in write.items():
+        f = fam(k)
+        if f:
+            agg[f][1] += 1024.0 * sum(vals)
+    out = {}
+    for f, (rd, wr, n) in agg.items():
+        out[f] = {"launches": n, "hbm_read_bytes_per_launch": rd / max(n, 1), "hbm_write_bytes_per_launch": wr / max(n, 1),
+                  "hbm_bytes_per_launch": (rd + wr) / max(n, 1)}
+    # the bench's op families split pw into fwd / bwd_data: report the pooled pw figure under both
+    if "pw" in out:
+        out["pw_fwd"] = out["pw"]
+        out["pw_bwd_data"] = out["pw"]
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for f, v in sorted(out.items()):
+        print("%-20s launches %5d  read %10.1f MB  write %10.1f MB per launch" %
+              (f, v["launches"], v["hbm_read_bytes_per_launch"] / 1e6, v["hbm_write_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()

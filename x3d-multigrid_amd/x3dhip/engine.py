@@ -394,7 +394,9 @@ class TrunkFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpooled):
-        sink = _GradSink(getattr(ctx.model, "_direct_grads", False), side_stream(dpooled.device))
+        import os
+        side = None if os.environ.get("X3D_NO_SIDE_STREAM") == "1" else side_stream(dpooled.device)
+        sink = _GradSink(getattr(ctx.model, "_direct_grads", False), side)
         trunk_backward(ctx.model, ctx.tctx, dpooled, sink)
         ctx.tctx = None
         out = []
