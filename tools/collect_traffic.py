@@ -18,8 +18,17 @@ FAMILY = [("pw_wgrad", "pw_bwd_weight"), ("pw2_kernel", "pw"), ("pw3_kernel", "p
 
 
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    """rocprofv3 7.2 writes a rocpd sqlite database by default (view counters_collection); older
+    --output-format csv runs leave *counter_collection.csv."""
     per = collections.defaultdict(list)
+    dbs = glob.glob(d + "/*.db") + glob.glob(d + "/*/*.db")
+    if dbs:
+        import sqlite3
+        con = sqlite3.connect(dbs[0])
+        for name, val in con.execute("select kernel_name, value from counters_collection where counter_name=?", (counter,)):
+            per[name].append(float(val))
+        return per
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
             per[r["Kernel_Name"]].append(float(r["Counter_Value"]))

@@ -206,26 +206,53 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs A) {
     }
 
     // ------------------------------ epilogue ------------------------------
+    // Per 16-row tile: phase 1 issues the four rows' global reads (activation-derivative input,
+    // its coefficients, the residual addend) from clamped addresses, phase 2 combines and stores
+    // -- no load sits under a per-lane branch (see pw2_kernel).
+    const bool has_add = EPI != EPI_STATS && A.addend != nullptr;
+    const bool add_s2 = has_add && A.addend_stride == 2;
     int aoff[NT];
-    if (EPI != EPI_STATS && A.addend != nullptr) {
+    bool av[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int p = p0 + j;
-            if (A.addend_stride == 2) {
-                const int hw = A.H * A.W;
-                const int t = p / hw, rem = p - t * hw;
-                const int h = rem / A.W, w = rem - h * A.W;
-                aoff[j] = (pv && !(h & 1) && !(w & 1)) ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : -1;
-            } else {
-                aoff[j] = pv ? p : -1;
-            }
+    for (int j = 0; j < NT; ++j) {
+        const int p = min(p0 + j, P - 1);
+        av[j] = has_add && pv;
+        aoff[j] = p;
+        if (add_s2) {
+            const int hw = A.H * A.W;
+            const int t = p / hw, rem = p - t * hw;
+            const int h = rem / A.W, w = rem - h * A.W;
+            const bool even = !(h & 1) && !(w & 1);
+            av[j] = av[j] && even;
+            aoff[j] = even ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0;
         }
     }
-    const long long addP = (A.addend_stride == 2) ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+    const int pc = pv ? p0 : 0;                   // clamped voxel (NT-aligned)
 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (mt < mt_run) {
+            float xv[4][NT], adv[4][NT], esc[4], esh[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = mt * 16 + 4 * q + e;
+                const size_t mrow = (size_t)n * A.M + m0 + (ml < bm ? ml : 0);
+                if (EPI == EPI_ACTBWD) {
+                    const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
+                    esc[e] = c2.x; esh[e] = c2.y;
+                    vload<NT>(A.ex + mrow * (size_t)P + pc, xv[e]);
+                }
+                if (has_add) {
+                    const float* pa = A.addend + mrow * (size_t)addP;
+                    if (NT == 4 && !add_s2) {
+                        vload<NT>(pa + pc, adv[e]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) adv[e][j] = pa[aoff[j]];
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = mt * 16 + 4 * q + e;
@@ -235,42 +262,29 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs A) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) v[j] = acc[mt][j][e];
                 float s1 = 0.f, s2 = 0.f;
-                if (mv && pv) {
-                    float* py = A.y + ((size_t)n * A.M + m) * (size_t)P + p0;
-                    if (EPI != EPI_STATS && A.addend != nullptr) {
-                        const float* pa = A.addend + ((size_t)n * A.M + m) * (size_t)addP;
-                        if (A.addend_stride == 1 && NT == 4) {
-                            float t4[NT];
-                            vload<NT>(pa + p0, t4);
+                if (has_add) {
 #pragma unroll
-                            for (int j = 0; j < NT; ++j) v[j] += t4[j];
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < NT; ++j) if (aoff[j] >= 0) v[j] += pa[aoff[j]];
-                        }
-                    }
-                    if (EPI == EPI_ACTBWD) {
-                        const float sc = A.ecoef[((size_t)n * A.M + m) * 2], sh = A.ecoef[((size_t)n * A.M + m) * 2 + 1];
-                        float xv[NT];
-                        vload<NT>(A.ex + ((size_t)n * A.M + m) * (size_t)P + p0, xv);
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            v[j] = v[j] * act_bwd(fmaf(sc, xv[j], sh), A.e_act);
-                            s1 += v[j];
-                            s2 = fmaf(v[j], xv[j], s2);
-                        }
-                    } else if (EPI == EPI_STATS) {
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
-                    }
-                    vstore<NT>(py, v);
+                    for (int j = 0; j < NT; ++j) v[j] += av[j] ? adv[e][j] : 0.f;
                 }
+                if (EPI == EPI_ACTBWD) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const float xj = pv ? xv[e][j] : 0.f;
+                        v[j] = pv ? v[j] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                        s1 += v[j];
+                        s2 = fmaf(v[j], xj, s2);
+                    }
+                } else if (EPI == EPI_STATS) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) { v[j] = pv ? v[j] : 0.f; s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+                }
+                if (mv && pv) vstore<NT>(A.y + ((size_t)n * A.M + m) * (size_t)P + p0, v);
                 if (EPI != EPI_PLAIN) {
                     s1 = row16_sum(s1);
                     s2 = row16_sum(s2);
                     if (r == 0) {
-                        red[(wave * MT * 16 + ml) * 2] = s1;
-                        red[(wave * MT * 16 + ml) * 2 + 1] = s2;
+                        red[(wave * MT * 16 + ml) * 2] = mv ? s1 : 0.f;
+                        red[(wave * MT * 16 + ml) * 2 + 1] = mv ? s2 : 0.f;
                     }
                 }
             }
@@ -323,11 +337,6 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
         const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
         off = (t * A.H + 2 * ho) * A.W + 2 * wo;
     }
-    if (IN != IN_RAW) {
-        for (int i = tid; i < K * NC; i += 256) Cl[i] = A.cin[(size_t)n * K * NC + i];
-        __syncthreads();
-    }
-
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -383,7 +392,11 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
         }
     };
 
-    issue(0, wa, xb, ab);
+    issue(0, wa, xb, ab);          // in flight while the coefficient table is filled
+    if (IN != IN_RAW) {
+        for (int i = tid; i < K * NC; i += 256) Cl[i] = A.cin[(size_t)n * K * NC + i];
+        __syncthreads();
+    }
     for (int s = 0; s < kgroups; s += 2) {
         if (s + 1 < kgroups) issue(s + 1, wn, xn, an_);
         compute(s, wa, xb, ab);
@@ -540,10 +553,6 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
     const int K = A.K, P = A.P;
     const int kgroups = (K + 15) / 16;
 
-    if (IN != IN_RAW) {
-        for (int i = tid; i < K * NC; i += 256) Cl[i] = A.cin[(size_t)n * K * NC + i];
-    }
-
     // ---- activation staging descriptors (chunk-invariant) ----------------------------------
     // 64 rows x 16 float4 columns = 1024 slots, four per thread
     int brow[P2_NB], bcol[P2_NB], boff[P2_NB][VEC ? 1 : 4];
@@ -675,9 +684,14 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
     };
 
     const int nchunks = (K + P2_KC - 1) / P2_KC;
-    __syncthreads();            // Cl visible
+    // the first activation / weight requests go out before the coefficient table is filled, so
+    // the two global round trips overlap
     fetch(0);
     fetch_a(0, a0, a1);
+    if (IN != IN_RAW) {
+        for (int i = tid; i < K * NC; i += 256) Cl[i] = A.cin[(size_t)n * K * NC + i];
+    }
+    __syncthreads();            // Cl visible
     store(0, 0);
     __syncthreads();
     for (int c = 0; c < nchunks; c += 2) {
@@ -694,79 +708,109 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
     }
 
     // ------------------------------ epilogue ------------------------------
+    // Phase 1 issues every global read of the epilogue (activation-derivative input, its BN
+    // coefficients, the residual addend) from clamped addresses with no divergent branch around
+    // them; phase 2 combines and stores.  (A load under a per-lane branch is waited for before
+    // the next branch: eight rows would pay eight serial memory round trips.)
     const int pl = p0 + 4 * r;                      // this lane's first voxel
     bool pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = pl + j < P;
+    const bool has_add = EPI != EPI_STATS && A.addend != nullptr;
+    const bool add_s2 = has_add && A.addend_stride == 2;
     int aoff[4];
+    bool av[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        pv[j] = pl + j < P;
-        aoff[j] = -1;
-        if (EPI != EPI_STATS && A.addend != nullptr && pv[j]) {
-            const int p = pl + j;
-            if (A.addend_stride == 2) {
-                const int hw = A.H * A.W;
-                const int t = p / hw, rem = p - t * hw;
-                const int h = rem / A.W, w = rem - h * A.W;
-                if (!(h & 1) && !(w & 1)) aoff[j] = (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1);
-            } else {
-                aoff[j] = p;
+        const int p = min(pl + j, P - 1);
+        av[j] = has_add && pv[j];
+        aoff[j] = p;
+        if (add_s2) {
+            const int hw = A.H * A.W;
+            const int t = p / hw, rem = p - t * hw;
+            const int h = rem / A.W, w = rem - h * A.W;
+            const bool even = !(h & 1) && !(w & 1);
+            av[j] = av[j] && even;
+            aoff[j] = even ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0;
+        }
+    }
+    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+    constexpr int NI = TWO ? 2 : 1;
+    float xv[NI][4][4], adv[NI][4][4], esc[NI][4], esh[NI][4];
+    bool mvv[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int lt = wave + 4 * i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ml = lt * 16 + 4 * q + e;
+            mvv[i][e] = lt < mt_run && ml < bm;
+            const size_t mrow = (size_t)n * A.M + m0 + (mvv[i][e] ? ml : 0);       // clamped to a valid row
+            if (EPI == EPI_ACTBWD) {
+                const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
+                esc[i][e] = c2.x; esh[i][e] = c2.y;
+                const float* px = A.ex + mrow * (size_t)P;
+                if (VEC) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(px + (pv[0] ? pl : 0));
+                    xv[i][e][0] = t4.x; xv[i][e][1] = t4.y; xv[i][e][2] = t4.z; xv[i][e][3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[i][e][j] = px[min(pl + j, P - 1)];
+                }
+            }
+            if (has_add) {
+                const float* pa = A.addend + mrow * (size_t)addP;
+                if (VEC && !add_s2) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(pa + (pv[0] ? pl : 0));
+                    adv[i][e][0] = t4.x; adv[i][e][1] = t4.y; adv[i][e][2] = t4.z; adv[i][e][3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) adv[i][e][j] = pa[aoff[j]];
+                }
             }
         }
     }
-    const long long addP = (A.addend_stride == 2) ? (long long)A.T * A.Ho * A.Wo : (long long)P;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int lt = wave + 4 * i;
-        if (lt < mt_run) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ml = lt * 16 + 4 * q + e;
-                const int m = m0 + ml;
-                const bool mv = ml < bm;
-                float v[4] = {acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]};
-                float s1 = 0.f, s2 = 0.f;
-                if (mv && pv[0]) {
-                    float* py = A.y + ((size_t)n * A.M + m) * (size_t)P + pl;
-                    if (EPI != EPI_STATS && A.addend != nullptr) {
-                        const float* pa = A.addend + ((size_t)n * A.M + m) * (size_t)addP;
+        for (int e = 0; e < 4; ++e) {
+            const int ml = lt * 16 + 4 * q + e;
+            const int m = m0 + ml;
+            const bool mv = mvv[i][e];
+            float v[4] = {acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]};
+            float s1 = 0.f, s2 = 0.f;
+            if (has_add) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (aoff[j] >= 0) v[j] += pa[aoff[j]];
-                    }
-                    if (EPI == EPI_ACTBWD) {
-                        const float sc = A.ecoef[((size_t)n * A.M + m) * 2], sh = A.ecoef[((size_t)n * A.M + m) * 2 + 1];
-                        const float* px = A.ex + ((size_t)n * A.M + m) * (size_t)P + pl;
-                        float xv[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (VEC) {
-                            const float4 t4 = *reinterpret_cast<const float4*>(px);
-                            xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w;
-                        } else {
+                for (int j = 0; j < 4; ++j) v[j] += av[j] ? adv[i][e][j] : 0.f;
+            }
+            if (EPI == EPI_ACTBWD) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) if (pv[j]) xv[j] = px[j];
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v[j] = pv[j] ? v[j] * act_bwd(fmaf(sc, xv[j], sh), A.e_act) : 0.f;
-                            s1 += v[j];
-                            s2 = fmaf(v[j], xv[j], s2);
-                        }
-                    } else if (EPI == EPI_STATS) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
-                    }
-                    if (VEC) {
-                        *reinterpret_cast<float4*>(py) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (pv[j]) py[j] = v[j];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const float xj = pv[j] ? xv[i][e][j] : 0.f;
+                    v[j] = pv[j] ? v[j] * act_bwd(fmaf(esc[i][e], xj, esh[i][e]), A.e_act) : 0.f;
+                    s1 += v[j];
+                    s2 = fmaf(v[j], xj, s2);
                 }
-                if (EPI != EPI_PLAIN && A.partial != nullptr) {
-                    s1 = row16_sum(s1);
-                    s2 = row16_sum(s2);
-                    if (r == 0 && mv) {
-                        A.partial[(((size_t)n * A.M + m) * A.tiles + tile) * 2] = s1;
-                        A.partial[(((size_t)n * A.M + m) * A.tiles + tile) * 2 + 1] = s2;
-                    }
+            } else if (EPI == EPI_STATS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = pv[j] ? v[j] : 0.f; s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+            }
+            if (mv && pv[0]) {
+                float* py = A.y + ((size_t)n * A.M + m) * (size_t)P + pl;
+                if (VEC) {
+                    *reinterpret_cast<float4*>(py) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (pv[j]) py[j] = v[j];
+                }
+            }
+            if (EPI != EPI_PLAIN && A.partial != nullptr) {
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
+                if (r == 0 && mv) {
+                    A.partial[(((size_t)n * A.M + m) * A.tiles + tile) * 2] = s1;
+                    A.partial[(((size_t)n * A.M + m) * A.tiles + tile) * 2 + 1] = s2;
                 }
             }
         }
