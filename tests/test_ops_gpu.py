@@ -59,6 +59,8 @@ PW_CASES = [
     (2, 432, 192, 2, 7, 7, 1, 2),     # LDS-tiled variant, K = 432, P % 4 != 0
     (1, 100, 130, 3, 6, 6, 1, 1),     # LDS-tiled, K % 4 == 0 but M not a multiple of 16
     (1, 70, 98, 2, 6, 6, 1, 0),       # LDS-tiled, K % 4 != 0 (scalar weight staging)
+    (20, 96, 112, 8, 14, 14, 1, 2),   # persistent tiled kernel: 800 items > grid (2 items per workgroup), 7 M-tiles (U = 4)
+    (20, 128, 96, 4, 16, 16, 1, 1),   # persistent tiled kernel: 4 chunks per item, 6 M-tiles (U = 3), item list with a tail
 ]
 
 

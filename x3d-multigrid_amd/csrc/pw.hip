@@ -14,6 +14,7 @@
 //   - the result is stored as float4 per lane (256 B contiguous per channel row).
 // BN statistics / BN-backward reductions ride in the epilogue: 16-lane DPP row sums, then
 // one partial per (sample, channel, voxel tile) -- summed later in fixed order (fp64).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -533,8 +534,21 @@ __global__ __launch_bounds__(256) void pw_pack_batch_kernel(const PackJob* __res
     J.wp[i] = (row < J.M && k < J.K) ? J.w[(size_t)row * J.ldm + (size_t)k * J.ldk] : 0.f;
 }
 
+#ifdef X3D_TRACE
+__device__ unsigned long long g_trace[16384 * 8];
+extern "C" int x3d_debug_trace(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), bytes);
+}
+#define TR(i) do { if (tid == 0) trv[i] = wall_clock64(); } while (0)
+#else
+#define TR(i) do { } while (0)
+#endif
+
 template <int IN, int EPI, bool VEC, bool TWO>
 __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
+#ifdef X3D_TRACE
+    unsigned long long trv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     __shared__ __attribute__((aligned(16))) float Bl[2][P2_KC * P2_BN];
     __shared__ float Cl[(IN == IN_RAW) ? 4 : 3 * PW_MAXK];
     constexpr int NC = (IN == IN_BNBWD) ? 3 : 2;
@@ -546,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
     const int tlo = blockIdx.x & 7, rest = blockIdx.x >> 3;
     const int mb = rest % A.mblocks, tile = (rest / A.mblocks) * 8 + tlo;
     if (tile >= A.tiles) return;
+    TR(0);
     const int mt_run = A.mt_run;                    // 16-row tiles in this M block (<= 8)
     const int m0 = mb * mt_run * 16;
     const int bm = min(mt_run * 16, A.M - m0);
@@ -691,9 +706,12 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
     if (IN != IN_RAW) {
         for (int i = tid; i < K * NC; i += 256) Cl[i] = A.cin[(size_t)n * K * NC + i];
     }
+    TR(1);
     __syncthreads();            // Cl visible
+    TR(2);
     store(0, 0);
     __syncthreads();
+    TR(3);
     for (int c = 0; c < nchunks; c += 2) {
         if (c + 1 < nchunks) { fetch(c + 1); fetch_a(c + 1, b0, b1); }
         compute(0, a0, a1);
@@ -707,6 +725,7 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
         }
     }
 
+    TR(4);
     // ------------------------------ epilogue ------------------------------
     // Phase 1 issues every global read of the epilogue (activation-derivative input, its BN
     // coefficients, the residual addend) from clamped addresses with no divergent branch around
@@ -770,6 +789,7 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
             }
         }
     }
+    TR(5);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int lt = wave + 4 * i;
@@ -815,12 +835,319 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
             }
         }
     }
+#ifdef X3D_TRACE
+    if (tid == 0) {
+        trv[6] = wall_clock64();
+        unsigned xcc = 0, hwid = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        trv[7] = ((unsigned long long)xcc << 32) | hwid;
+        const size_t id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        if (id < 16384)
+            for (int i = 0; i < 8; ++i) g_trace[id * 8 + i] = trv[i];
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of the tiled kernel for dense inputs with P % 4 == 0.
+// pw2_kernel's workgroups all start together and run load -> MFMA -> store in lock step, so
+// the memory phases and the MFMA phase never overlap (per-workgroup timeline:
+// profiles/r01/pw2_timeline.txt).  Here a workgroup walks a strided list of work items
+// (sample, 64-voxel tile, M block) as ONE flat sequence of 32-channel chunks:
+//   * the global reads of chunk g+1 (activations, per-channel coefficients, packed weight
+//     fragments) are issued before the MFMAs of chunk g and written to the other LDS buffer
+//     after them -- one barrier per chunk, item boundaries included, so the epilogue stores of
+//     item i overlap the loads of item i+1;
+//   * no per-sample coefficient table in LDS: the (<= 3) coefficients of a staged channel row
+//     ride along with its activation float4;
+//   * work split inside the workgroup: unit = (16-row M tile, 32-voxel half tile); wave w owns
+//     half (w & 1) and M tiles (w >> 1) + 2j, j < U, so 6 M tiles (96 channels) occupy all four
+//     waves evenly (pw2_kernel: 75 %).
+//   * item -> workgroup map keeps the M blocks of one voxel tile on one XCD (ids differ by 8).
+// ---------------------------------------------------------------------------------------
+constexpr int P4_BN = 64, P4_KC = 32, P4_PITCH = 72;     // pitch 72: the four k rows of a b64 fragment read hit disjoint banks
+
+template <int IN, int EPI, int U>
+__global__ __launch_bounds__(256, 2) void pw4_kernel(const PwArgs A) {
+    __shared__ __attribute__((aligned(16))) float Bl[2][P4_KC * P4_PITCH];
+    __shared__ float red[(EPI == EPI_PLAIN) ? 4 : 4 * U * 16 * 2];
+    constexpr int NC = (IN == IN_BNBWD) ? 3 : 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int half = wave & 1, mpar = wave >> 1;
+    const int K = A.K, P = A.P, M = A.M;
+    const int kgroups = (K + 15) / 16, nchunks = (K + P4_KC - 1) / P4_KC;
+    const int mt_run = A.mt_run, mblocks = A.mblocks;
+    const int per_n = ((A.tiles + 7) / 8) * 8 * mblocks;
+    const int items = per_n * A.N;
+    const int mtl = (M + 15) / 16 - 1;              // last packed M tile
+    const int G = gridDim.x;
+
+    auto decode = [&](int it, int& n, int& tile, int& mb) {
+        n = it / per_n;
+        const int rem = it - n * per_n;
+        const int tlo = rem & 7, rest = rem >> 3;
+        mb = rest % mblocks;
+        tile = (rest / mblocks) * 8 + tlo;
+    };
+    auto next_valid = [&](int it, int& n, int& tile, int& mb) {
+        while (it < items) {
+            decode(it, n, tile, mb);
+            if (tile < A.tiles) break;
+            it += G;
+        }
+        return it;
+    };
+
+    // staging slots of this thread: rows (tid >> 4) and (tid >> 4) + 16 of a chunk, voxels col..col+3
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
+
+    float4 rb[2], rba[(IN == IN_BNBWD) ? 2 : 1];
+    float cf[2][NC];
+    bool okm[2];
+
+    auto prefetch = [&](int n, int tile, int c) {
+        const int p = tile * P4_BN + scol;
+        const bool pvalid = p < P;
+        const int poff = pvalid ? p : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = c * P4_KC + srow + 16 * i;
+            const int kc = min(k, K - 1);
+            okm[i] = pvalid && k < K;
+            const size_t rowi = (size_t)n * K + kc;
+            rb[i] = *reinterpret_cast<const float4*>(A.x + rowi * (size_t)P + poff);
+            if (IN == IN_BNBWD) rba[i] = *reinterpret_cast<const float4*>(A.a + rowi * (size_t)P + poff);
+            if (IN == IN_AFFACT) {
+                const float2 c2 = *reinterpret_cast<const float2*>(A.cin + rowi * 2);
+                cf[i][0] = c2.x; cf[i][1] = c2.y;
+            } else if (IN == IN_BNBWD) {
+                const float* pc = A.cin + rowi * 3;
+                cf[i][0] = pc[0]; cf[i][1] = pc[1]; cf[i][2 % NC] = pc[2];
+            }
+        }
+    };
+
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+            if (IN == IN_BNBWD) {
+                const float av[4] = {rba[i].x, rba[i].y, rba[i].z, rba[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(cf[i][0], v[e], fmaf(cf[i][1], av[e], cf[i][2 % NC]));
+            } else if (IN == IN_AFFACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(cf[i][0], v[e], cf[i][1]), A.in_act);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = okm[i] ? v[e] : 0.f;
+            *reinterpret_cast<float4*>(&Bl[buf][(srow + 16 * i) * P4_PITCH + scol]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+
+    auto fetch_a = [&](int mb, int c, float4 (&d)[U][2]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int mt = min(mb * mt_run + mpar + 2 * j, mtl);             // clamped: duplicates are never stored
+            const float* base = A.wp + (size_t)mt * kgroups * 256 + lane * 4;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int sg = min(2 * c + s2, kgroups - 1);                 // clamped: the extra group meets zero B rows
+                d[j][s2] = *reinterpret_cast<const float4*>(base + (size_t)sg * 256);
+            }
+        }
+    };
+
+    f32x4 acc[U][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < U; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    };
+
+    auto compute = [&](int buf, const float4 (&a)[U][2]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 b = *reinterpret_cast<const float2*>(&Bl[buf][(s2 * 16 + 4 * q + e) * P4_PITCH + 32 * half + 2 * r]);
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const float av = e == 0 ? a[j][s2].x : (e == 1 ? a[j][s2].y : (e == 2 ? a[j][s2].z : a[j][s2].w));
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.x, acc[j][0], 0, 0, 0);
+                    acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.y, acc[j][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const bool has_add = EPI != EPI_STATS && A.addend != nullptr;
+    const bool add_s2 = has_add && A.addend_stride == 2;
+    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+
+    auto epilogue = [&](int n, int tile, int mb) {
+        const int m0 = mb * mt_run * 16;
+        const int bm = min(mt_run * 16, M - m0);
+        const int pl = tile * P4_BN + 32 * half + 2 * r;       // this lane's two voxels (P even: both or none valid)
+        const bool pv = pl < P;
+        const int pc = pv ? pl : 0;
+        int aoff[2] = {pc, pc + 1};
+        bool av[2] = {has_add && pv, has_add && pv};
+        if (add_s2) {
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int p = pc + j2;
+                const int hw = A.H * A.W;
+                const int t = p / hw, rem = p - t * hw;
+                const int h = rem / A.W, w = rem - h * A.W;
+                const bool even = !(h & 1) && !(w & 1);
+                av[j2] = av[j2] && even;
+                aoff[j2] = even ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int lt = mpar + 2 * j;
+            // phase 1: the four rows' reads, branch-free from clamped addresses
+            float xv[4][2], adv[4][2], esc[4], esh[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = lt * 16 + 4 * q + e;
+                const size_t mrow = (size_t)n * M + m0 + ((lt < mt_run && ml < bm) ? ml : 0);
+                if (EPI == EPI_ACTBWD) {
+                    const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
+                    esc[e] = c2.x; esh[e] = c2.y;
+                    const float2 t2 = *reinterpret_cast<const float2*>(A.ex + mrow * (size_t)P + pc);
+                    xv[e][0] = t2.x; xv[e][1] = t2.y;
+                }
+                if (has_add) {
+                    const float* pa = A.addend + mrow * (size_t)addP;
+                    if (!add_s2) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(pa + pc);
+                        adv[e][0] = t2.x; adv[e][1] = t2.y;
+                    } else {
+                        adv[e][0] = pa[aoff[0]]; adv[e][1] = pa[aoff[1]];
+                    }
+                }
+            }
+            // phase 2
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = lt * 16 + 4 * q + e;
+                const bool mv = lt < mt_run && ml < bm;
+                float v[2] = {acc[j][0][e], acc[j][1][e]};
+                float s1 = 0.f, s2 = 0.f;
+                if (has_add) { v[0] += av[0] ? adv[e][0] : 0.f; v[1] += av[1] ? adv[e][1] : 0.f; }
+                if (EPI == EPI_ACTBWD) {
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const float xj = pv ? xv[e][j2] : 0.f;
+                        v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                        s1 += v[j2];
+                        s2 = fmaf(v[j2], xj, s2);
+                    }
+                } else if (EPI == EPI_STATS) {
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2) { v[j2] = pv ? v[j2] : 0.f; s1 += v[j2]; s2 = fmaf(v[j2], v[j2], s2); }
+                }
+                if (mv && pv)
+                    *reinterpret_cast<float2*>(A.y + ((size_t)n * M + m0 + ml) * (size_t)P + pl) = make_float2(v[0], v[1]);
+                if (EPI != EPI_PLAIN) {
+                    s1 = row16_sum(s1);
+                    s2 = row16_sum(s2);
+                    if (r == 0) {
+                        red[((wave * U + j) * 16 + 4 * q + e) * 2] = mv ? s1 : 0.f;
+                        red[((wave * U + j) * 16 + 4 * q + e) * 2 + 1] = mv ? s2 : 0.f;
+                    }
+                }
+            }
+        }
+        if (EPI != EPI_PLAIN && A.partial != nullptr) {
+            __syncthreads();
+            // one partial per (row, 64-voxel tile): the two half-tile waves of a row are summed here
+            for (int idx = tid; idx < bm * 2; idx += 256) {
+                const int ml = idx >> 1, which = idx & 1;
+                const int lt = ml >> 4, wv = (lt & 1) * 2, j = lt >> 1;
+                const float s = red[(((wv)*U + j) * 16 + (ml & 15)) * 2 + which] +
+                                red[(((wv + 1) * U + j) * 16 + (ml & 15)) * 2 + which];
+                A.partial[(((size_t)n * M + (m0 + ml)) * A.tiles + tile) * 2 + which] = s;
+            }
+        }
+    };
+
+    // ---------------------------------- flat pipeline ----------------------------------
+    int n = 0, tile = 0, mb = 0;
+    int it = next_valid(blockIdx.x, n, tile, mb);
+    if (it >= items) return;
+#ifdef X3D_TRACE
+    unsigned long long trv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int tri = 1;
+    trv[0] = wall_clock64();
+#define TRN() do { if (tri < 7) trv[tri++] = wall_clock64(); } while (0)
+#else
+#define TRN() do { } while (0)
+#endif
+    int pn = n, ptile = tile, pmb = mb, pit = it, pc_ = 0;          // prefetch cursor: chunk pc_ of item pit
+    auto advance = [&]() {
+        if (++pc_ == nchunks) { pc_ = 0; pit = next_valid(pit + G, pn, ptile, pmb); }
+    };
+    float4 a0[U][2], a1[U][2];
+    prefetch(pn, ptile, 0);
+    fetch_a(pmb, 0, a0);
+    advance();
+    zero_acc();
+    int c = 0;
+    for (;;) {
+        store(0);
+        __syncthreads();
+        bool more = pit < items;
+        if (more) { prefetch(pn, ptile, pc_); fetch_a(pmb, pc_, a1); advance(); }
+        compute(0, a0);
+        if (++c == nchunks) { TRN(); epilogue(n, tile, mb); TRN(); zero_acc(); c = 0; it = next_valid(it + G, n, tile, mb); }
+        if (!more) break;
+        store(1);
+        __syncthreads();
+        more = pit < items;
+        if (more) { prefetch(pn, ptile, pc_); fetch_a(pmb, pc_, a0); advance(); }
+        compute(1, a1);
+        if (++c == nchunks) { TRN(); epilogue(n, tile, mb); TRN(); zero_acc(); c = 0; it = next_valid(it + G, n, tile, mb); }
+        if (!more) break;
+    }
+#ifdef X3D_TRACE
+    if (tid == 0) {
+        unsigned xcc = 0, hwid = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        trv[7] = ((unsigned long long)xcc << 32) | hwid;
+        if (blockIdx.x < 16384)
+            for (int i = 0; i < 8; ++i) g_trace[(size_t)blockIdx.x * 8 + i] = trv[i];
+    }
+#endif
 }
 
 // One decision function for kernel variant and tile count (the caller sizes `partial` with it).
 // variant: 0 = streaming NT=4, 1 = streaming NT=1, 2 = LDS-tiled (pw2)
 static void pw_plan(int N, int K, int M, int P, bool dense, int* variant, int* tiles, int* mblocks, int* mt_run) {
     const int mtiles = cdiv(M, 16);
+    static const bool no_persist = getenv("X3D_PW_NO_PERSIST") != nullptr;      // A/B knob for tools/microbench.py
+    if (K >= 64 && M >= 96 && dense && (P % 4 == 0) && !no_persist) {
+        // persistent pipelined kernel: units of (M tile, half voxel tile), U = ceil(mt_run / 2) per wave;
+        // fewest M blocks (each restages the activation tile) unless one more block removes a whole unit row
+        *variant = 3;
+        int best_mb = cdiv(mtiles, 8), best_cost = 1 << 30;
+        for (int mbk = cdiv(mtiles, 8); mbk <= cdiv(mtiles, 8) + 1; ++mbk) {
+            const int run = cdiv(mtiles, mbk);
+            const int cost = mbk * cdiv(run, 2);
+            if (cost < best_cost) { best_cost = cost; best_mb = mbk; }
+        }
+        *mblocks = best_mb;
+        *mt_run = cdiv(mtiles, best_mb);
+        *tiles = cdiv(P, P4_BN);
+        return;
+    }
     if (K >= 64 && M >= 96) {
         *variant = 2;
         // waves own tiles {w, w+4}: a block of 5..8 tiles costs two tile-times, 1..4 tiles one;
@@ -851,7 +1178,17 @@ int launch_pw(PwArgs& A, hipStream_t s) {
     const bool dense = !A.strided && (A.Pin % 4 == 0);
     pw_plan(A.N, A.K, A.M, A.P, dense, &variant, &A.tiles, &A.mblocks, &A.mt_run);
     dim3 grid(cdiv(A.tiles, 8) * 8 * A.mblocks, A.N), block(256);
-    if (variant == 2 && A.wp == nullptr) {      // no packed weights: streaming kernel on the same 64-voxel tiles
+    if (variant == 3 && A.wp != nullptr) {
+        const int items = cdiv(A.tiles, 8) * 8 * A.mblocks * A.N;
+        dim3 pgrid(min(items, 512));            // two resident workgroups per CU walk the item list
+        const int U = cdiv(A.mt_run, 2);
+        if (U <= 2) hipLaunchKernelGGL((pw4_kernel<IN, EPI, 2>), pgrid, block, 0, s, A);
+        else if (U == 3) hipLaunchKernelGGL((pw4_kernel<IN, EPI, 3>), pgrid, block, 0, s, A);
+        else hipLaunchKernelGGL((pw4_kernel<IN, EPI, 4>), pgrid, block, 0, s, A);
+        X3D_LAUNCH_CHECK();
+        return X3D_OK;
+    }
+    if (variant >= 2 && A.wp == nullptr) {      // no packed weights: streaming kernel on the same 64-voxel tiles
         variant = 1;
         const int mtiles = cdiv(A.M, 16);
         A.mblocks = cdiv(mtiles, 4);
