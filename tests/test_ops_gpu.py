@@ -152,6 +152,10 @@ DW_CASES = [
     (1, 3, 2, 56, 56, 1),     # one channel per workgroup (scalar-weight variant), T = 2
     (1, 3, 4, 112, 112, 2),
     (16, 108, 2, 6, 6, 1),    # many small workgroups (caught a slot-reuse race in the T march)
+    (2, 10, 16, 14, 14, 1),   # stage-3 geometry, T = 16
+    (2, 3, 8, 28, 28, 1),     # stage-2 geometry
+    (2, 3, 8, 28, 28, 2),     # stage-3.0 geometry (stride 2)
+    (40, 20, 4, 7, 7, 1),     # many workgroups, tail group of channels
 ]
 
 

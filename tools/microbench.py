@@ -15,16 +15,24 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 
 
 def t(fn):
+    """us per launch: `reps` launches captured into one hipGraph and replayed (a Python/ctypes call costs
+    ~25 us, more than most of these kernels run, so eager back-to-back timing measures the host)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for _ in range(5):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1000
+    return e0.elapsed_time(e1) / (5 * reps) * 1000
 
 
 cases = {

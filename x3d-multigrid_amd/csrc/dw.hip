@@ -98,24 +98,23 @@ __device__ __forceinline__ void make_chunks(const DwGeom& g, int n, int c0, int 
     }
 }
 
+// Branch-free: every chunk is loaded unconditionally from a clamped address (chunks outside the
+// tensor / beyond T read element 0 of the sample) and masked when it is written to LDS.  A load
+// under a divergent branch makes the compiler drain vmcnt -- including the previous step's output
+// stores -- at the top of every T step.
 template <int NCH, bool VEC>
 __device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chunk (&ch)[NCH], int toff, bool tvalid,
                                        float4 (&reg)[NCH]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tvalid && ch[i].goff >= 0) {
-            const float* p = base + ch[i].goff + toff;
-            if (VEC) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                v.x = p[0];
-                if (ch[i].nval > 1) v.y = p[1];
-                if (ch[i].nval > 2) v.z = p[2];
-                if (ch[i].nval > 3) v.w = p[3];
-            }
+        const bool ok = tvalid && ch[i].goff >= 0;
+        const float* p = base + (ok ? ch[i].goff + toff : 0);
+        if (VEC) {
+            reg[i] = *reinterpret_cast<const float4*>(p);
+        } else {
+            const int nv = ok ? ch[i].nval : 1;
+            reg[i] = make_float4(p[0], p[nv > 1 ? 1 : 0], p[nv > 2 ? 2 : 0], p[nv > 3 ? 3 : 0]);
         }
-        reg[i] = v;
     }
 }
 
@@ -142,9 +141,21 @@ __device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], b
 // Forward.  LDS holds two planes (double buffer); every thread keeps the values of the three
 // planes its stencil touches in registers (sliding window along T), so each staged value is
 // read from LDS once per consumer instead of three times.
+#ifdef X3D_TRACE
+__device__ unsigned long long g_dwtrace[16384 * 8];
+extern "C" int x3d_debug_dwtrace(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dwtrace), bytes); }
+#define DTR(i) do { if (threadIdx.x == 0) dtr[i] = wall_clock64(); } while (0)
+#else
+#define DTR(i) do { } while (0)
+#endif
+
 template <int NCH, int STRIDE, bool UNI, bool VEC>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef X3D_TRACE
+    unsigned long long dtr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    DTR(0);
     constexpr int NV = (STRIDE == 1) ? 18 : 27;          // window values per plane
     const DwGeom& g = A.g;
     const int tid = threadIdx.x;
@@ -206,12 +217,17 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     float s1 = 0.f, s2 = 0.f;
     const size_t ybase = (((size_t)n * g.C + c) * g.T) * (size_t)g.Ho * g.Wo + (size_t)(ho0 + row) * g.Wo + grp * 4;
 
-    // one T step: window planes (wa, wb, wc) = (t-1, t, t+1)
+    // one T step: window planes (wa, wb, wc) = (t-1, t, t+1).
+    // Order matters on gfx9-family hardware (ONE vmcnt for loads and stores, and the compiler waits
+    // vmcnt(0) for a load whenever a store may also be pending): the plane t+2 loads are consumed
+    // (written to LDS) BEFORE this step's output store is issued, so no wait ever sits behind a
+    // fresh store; the store's ack then hides under the next step's stencil.
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
+        if (t == 5) DTR(2);
         fetch4<NCH, VEC>(xb, ch, (t + 2) * plane, t + 2 < g.T, reg);    // in flight during the stencil
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
             read_plane(ring + (size_t)((t + 1) & 1) * g.slot, wc);
-            float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
                 const float(&v)[NV] = kt == 0 ? wa : (kt == 1 ? wb : wc);
@@ -225,22 +241,32 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
                                     fmaf(w2, v[kh * RS + i * STRIDE + 2], o[i])));
                 }
             }
+            if (!VEC) {
+                const int wo = grp * 4;
+#pragma unroll
+                for (int i = 1; i < 4; ++i) if (wo + i >= g.Wo) o[i] = 0.f;
+            }
+            s1 += (o[0] + o[1]) + (o[2] + o[3]);
+            s2 = fmaf(o[0], o[0], fmaf(o[1], o[1], fmaf(o[2], o[2], fmaf(o[3], o[3], s2))));
+        }
+        if (t == 5) DTR(3);
+        // slot t&1 held plane t, last read one barrier ago -> free for plane t+2
+        store_act<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, A.pre_act, reg);
+        if (t == 5) DTR(4);
+        if (valid) {
             float* py = A.y + ybase + (size_t)t * g.Ho * g.Wo;
             const int wo = grp * 4;
             if (VEC) {
                 *reinterpret_cast<float4*>(py) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
                 py[0] = o[0];
-                if (wo + 1 < g.Wo) py[1] = o[1]; else o[1] = 0.f;
-                if (wo + 2 < g.Wo) py[2] = o[2]; else o[2] = 0.f;
-                if (wo + 3 < g.Wo) py[3] = o[3]; else o[3] = 0.f;
+                if (wo + 1 < g.Wo) py[1] = o[1];
+                if (wo + 2 < g.Wo) py[2] = o[2];
+                if (wo + 3 < g.Wo) py[3] = o[3];
             }
-            s1 += (o[0] + o[1]) + (o[2] + o[3]);
-            s2 = fmaf(o[0], o[0], fmaf(o[1], o[1], fmaf(o[2], o[2], fmaf(o[3], o[3], s2))));
         }
-        // slot t&1 held plane t, last read one barrier ago -> free for plane t+2
-        store_act<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, A.pre_act, reg);
         __syncthreads();
+        if (t == 5) DTR(5);
     };
 
     float w0[NV], w1[NV], w2[NV];
@@ -248,11 +274,13 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     for (int i = 0; i < NV; ++i) { w0[i] = 0.f; w1[i] = 0.f; w2[i] = 0.f; }
     if (valid) read_plane(ring, w1);                     // plane 0
     __syncthreads();       // step 0 overwrites slot 0: every wave must have read plane 0 first
+    DTR(1);
     for (int t = 0; t < g.T; t += 3) {
         step(t, w0, w1, w2);
         if (t + 1 < g.T) step(t + 1, w1, w2, w0);
         if (t + 2 < g.T) step(t + 2, w2, w0, w1);
     }
+    DTR(6);
 
     if (A.partial != nullptr) {
         redbuf[tid * 2] = valid ? s1 : 0.f;
@@ -267,6 +295,13 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
             }
         }
     }
+#ifdef X3D_TRACE
+    if (tid == 0) {
+        dtr[7] = wall_clock64();
+        const size_t id = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (id < 16384) for (int i = 0; i < 8; ++i) g_dwtrace[id * 8 + i] = dtr[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -391,20 +426,31 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     float s1 = 0.f, s2 = 0.f;
     const size_t xbase = (((size_t)n * g.C + c) * g.T) * (size_t)g.H * g.W + (size_t)h * g.W + w0;
 
+    // raw input of one step: unconditional load from a clamped address (see fetch4), one step ahead
+    float xnext[4];
+    auto load_x = [&](int t) {
+        const bool ok = valid && t < g.T;
+        const float* px = A.x + (ok ? xbase + (size_t)t * g.H * g.W : 0);
+        if (VEC) {
+            const float4 qv = *reinterpret_cast<const float4*>(px);
+            xnext[0] = qv.x; xnext[1] = qv.y; xnext[2] = qv.z; xnext[3] = qv.w;
+        } else {
+            const int rem = ok ? g.W - w0 : 1;
+            xnext[0] = px[0]; xnext[1] = px[rem > 1 ? 1 : 0]; xnext[2] = px[rem > 2 ? 2 : 0]; xnext[3] = px[rem > 3 ? 3 : 0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) xnext[i] = i < rem ? xnext[i] : 0.f;
+        }
+    };
+    load_x(0);
+
     // window planes (wa, wb, wc) = dY planes (t-1, t, t+1); time tap kt uses plane t+1-kt
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
         fetch4<NCH, VEC>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, rg);
         fetch4<NCH, VEC>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, ra);
+        float xv[4] = {xnext[0], xnext[1], xnext[2], xnext[3]};      // loaded one step ago, complete since the last LDS staging
+        load_x(t + 1);                                               // next step's raw input, in flight during the stencil
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
-            const float* px = A.x + xbase + (size_t)t * g.H * g.W;
-            float xv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (VEC) {
-                const float4 qv = *reinterpret_cast<const float4*>(px);
-                xv[0] = qv.x; xv[1] = qv.y; xv[2] = qv.z; xv[3] = qv.w;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) if (w0 + i < g.W) xv[i] = px[i];
-            }
             read_plane(ring + (size_t)((t + 1) & 1) * g.slot, wc);
             float hin[4], dact[4], d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -456,13 +502,16 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
                     }
                 }
             }
-            float o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 o[i] = d[i] * dact[i];
                 s1 += o[i];
                 s2 = fmaf(o[i], xv[i], s2);
             }
+        }
+        // all loads of this step (dY plane t+2, x of step t+1) are consumed before the output store is issued
+        store_dy<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, k0, k1, k2, rg, ra);
+        if (valid) {
             float* po = A.out + xbase + (size_t)t * g.H * g.W;
             if (VEC) {
                 *reinterpret_cast<float4*>(po) = make_float4(o[0], o[1], o[2], o[3]);
@@ -471,7 +520,6 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
                 for (int i = 0; i < 4; ++i) if (w0 + i < g.W) po[i] = o[i];
             }
         }
-        store_dy<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, k0, k1, k2, rg, ra);
         __syncthreads();
     };
 

@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256, 2) void pw4_kernel(const PwArgs A) {
 // variant: 0 = streaming NT=4, 1 = streaming NT=1, 2 = LDS-tiled (pw2)
 static void pw_plan(int N, int K, int M, int P, bool dense, int* variant, int* tiles, int* mblocks, int* mt_run) {
     const int mtiles = cdiv(M, 16);
-    static const bool no_persist = getenv("X3D_PW_NO_PERSIST") != nullptr;      // A/B knob for tools/microbench.py
+    const bool no_persist = getenv("X3D_PW_NO_PERSIST") != nullptr;      // A/B knob (tests, tools/microbench.py); read per call
     if (K >= 64 && M >= 96 && dense && (P % 4 == 0) && !no_persist) {
         // persistent pipelined kernel: units of (M tile, half voxel tile), U = ceil(mt_run / 2) per wave;
         // fewest M blocks (each restages the activation tile) unless one more block removes a whole unit row
