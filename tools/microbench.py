@@ -58,6 +58,17 @@ if which.startswith("pw"):
     print("%s fwd(affine+swish): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
     us = t(lambda: ops.pw_fwd(x, w, out=y, wp=wp))
     print("%s fwd(raw): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
+elif which.startswith("wg"):
+    N, Ci, Co, T, H, W = cases["pw" + which[2:]]
+    x = torch.randn(N, Ci, T, H, W, device=dev)
+    g = torch.randn(N, Co, T, H, W, device=dev)
+    a = torch.randn(N, Co, T, H, W, device=dev)
+    cb = torch.rand(N, Co, 3, device=dev)
+    pre = torch.rand(N, Ci, 2, device=dev)
+    us = t(lambda: ops.pw_bwd_weight(g, a, cb, x, (Co, Ci), pre=pre, pre_act=2))
+    fl = 2.0 * N * Ci * Co * T * H * W
+    by = 4.0 * N * (Ci + 2 * Co) * T * H * W
+    print("%s wgrad(+reduce): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
 elif which.startswith("dw"):
     shapes = {"dw_l1": (8, 54, 16, 56, 56, 1), "dw_l10": (8, 54, 16, 112, 112, 2), "dw_l2": (8, 108, 16, 28, 28, 1),
               "dw_l3": (8, 216, 16, 14, 14, 1), "dw_l4": (8, 432, 16, 7, 7, 1)}

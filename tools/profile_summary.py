@@ -4,6 +4,7 @@ as a small CSV for profiles/.
     python tools/profile_summary.py <results.db> <out.csv>
 """
 import csv
+import re
 import sqlite3
 import sys
 
@@ -18,7 +19,8 @@ def main():
             w.writerow([name, calls, "%.3f" % total, "%.3f" % avg, "%.3f" % pct])
     fam = {}
     for name, calls, total, avg, pct in rows:
-        key = name.split("(anonymous namespace)::")[-1].split("<")[0].split("(")[0]
+        m = re.search(r"::(\w+)", name)
+        key = m.group(1) if m else name.split("(")[0]
         c, t = fam.get(key, (0, 0.0))
         fam[key] = (c + calls, t + total)
     for key, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:16]:

@@ -238,13 +238,11 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ c
 // extra (optional, SE variant): per-(n,c) arrays modifying the upstream gradient
 //   g_full = se[n,c]*g + dpool[n,c]/count
 // ------------------------------------------------------------------------------------
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ dsum, int N, int C, int S, int count,
+__device__ __forceinline__ void bn_bwd_finalize_channel(int c, const double* __restrict__ dsum, int N, int C, int S, int count,
                                        const float* __restrict__ gamma, const float* __restrict__ save,
                                        const float* __restrict__ se, const float* __restrict__ dpool,
                                        const float* __restrict__ nsum, float* __restrict__ cb,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
     const double M = (double)count * (double)(N / S);
     const double g = gamma[c];
     double dg = 0.0, db = 0.0;
@@ -288,6 +286,16 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ dsum, int N, i
     }
 }
 
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ dsum, int N, int C, int S, int count,
+                                       const float* __restrict__ gamma, const float* __restrict__ save,
+                                       const float* __restrict__ se, const float* __restrict__ dpool,
+                                       const float* __restrict__ nsum, float* __restrict__ cb,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    bn_bwd_finalize_channel(c, dsum, N, C, S, count, gamma, save, se, dpool, nsum, cb, dgamma, dbeta, accumulate);
+}
+
 // SE backward, one workgroup per sample.  Writes dpool[n][c], dz2[n][c], dz1[n][w].
 __global__ __launch_bounds__(256) void se_bwd_sample_kernel(
     const double* __restrict__ dsum, int C, int S, int Wd, const float* __restrict__ gamma,
@@ -328,12 +336,10 @@ __global__ __launch_bounds__(256) void se_bwd_sample_kernel(
 }
 
 // SE weight gradients: thread per (c, w) pair; sums over samples in order.
-__global__ void se_wgrad_kernel(int N, int C, int Wd, const float* __restrict__ dz2, const float* __restrict__ dz1,
+__device__ __forceinline__ void se_wgrad_element(int i, int N, int C, int Wd, const float* __restrict__ dz2, const float* __restrict__ dz1,
                                 const float* __restrict__ save_z, const float* __restrict__ save_pool,
                                 float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
                                 float* __restrict__ db2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * Wd) return;
     const int c = i / Wd, w = i - c * Wd;
     double a2 = 0.0, a1 = 0.0, bb2 = 0.0, bb1 = 0.0;
     for (int n = 0; n < N; ++n) {
@@ -347,6 +353,26 @@ __global__ void se_wgrad_kernel(int N, int C, int Wd, const float* __restrict__ 
     dw1[(size_t)w * C + c] = (float)a1;
     if (w == 0) db2[c] = (float)bb2;
     if (c == 0) db1[w] = (float)bb1;
+}
+
+// One launch for the two independent consumers of the per-sample SE backward: blocks [0, nbw) compute the SE weight
+// gradients, the remaining blocks the BN-backward coefficients / dgamma / dbeta of the SE-scaled BN.
+__global__ __launch_bounds__(256) void se_tail_kernel(int nbw, const double* __restrict__ dsum, int N, int C, int S, int count,
+                                                      int Wd, const float* __restrict__ gamma, const float* __restrict__ save,
+                                                      const float* __restrict__ se, const float* __restrict__ dpool,
+                                                      const float* __restrict__ nsum, float* __restrict__ cb,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      const float* __restrict__ dz2, const float* __restrict__ dz1,
+                                                      const float* __restrict__ save_z, const float* __restrict__ save_pool,
+                                                      float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                      float* __restrict__ db2) {
+    if ((int)blockIdx.x < nbw) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < C * Wd) se_wgrad_element(i, N, C, Wd, dz2, dz1, save_z, save_pool, dw1, db1, dw2, db2);
+    } else {
+        const int c = ((int)blockIdx.x - nbw) * 256 + threadIdx.x;
+        if (c < C) bn_bwd_finalize_channel(c, dsum, N, C, S, count, gamma, save, se, dpool, nsum, cb, dgamma, dbeta, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -576,10 +602,9 @@ extern "C" int x3d_se_bn_bwd_finalize(const float* partial, int N, int C, int ti
     hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
     hipLaunchKernelGGL(se_bwd_sample_kernel, dim3(N), dim3(256), 0, s, dsum, C, S, Wd, gamma, beta, save, w1, w2,
                        save_se, save_z, dpool, dz2, dz1);
-    hipLaunchKernelGGL(se_wgrad_kernel, dim3(cdiv(C * Wd, 256)), dim3(256), 0, s, N, C, Wd, dz2, dz1, save_z,
-                       save_pool, dw1, db1, dw2, db2);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dsum, N, C, S, count, gamma, save,
-                       save_se, dpool, nsum, cb, dgamma, dbeta, 0);
+    const int nbw = cdiv(C * Wd, 256);
+    hipLaunchKernelGGL(se_tail_kernel, dim3(nbw + cdiv(C, 256)), dim3(256), 0, s, nbw, dsum, N, C, S, count, Wd, gamma, save,
+                       save_se, dpool, nsum, cb, dgamma, dbeta, dz2, dz1, save_z, save_pool, dw1, db1, dw2, db2);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

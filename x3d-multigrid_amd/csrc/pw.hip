@@ -1569,8 +1569,10 @@ static void wgrad_plan(int N, int P, int Co, int Ci, bool dense, int* tiled, int
         *cob = cdiv(Co, W2_CO); *cib = cdiv(Ci, W2_CI);
         *ct_run = 8; *it_run = 4;
         const int chunks = N * cdiv(P, W2_PT);
-        int g = cdiv(chunks, 6);                                   // ~6 chunks per workgroup ...
-        const int cap = 640 / ((*cob) * (*cib)) > 16 ? 640 / ((*cob) * (*cib)) : 16;   // ... but <= ~640 workgroups
+        static const int cpw = getenv("X3D_WG_CPW") ? atoi(getenv("X3D_WG_CPW")) : 6;
+        static const int wcap = getenv("X3D_WG_CAP") ? atoi(getenv("X3D_WG_CAP")) : 640;
+        int g = cdiv(chunks, cpw);                                   // ~6 chunks per workgroup ...
+        const int cap = wcap / ((*cob) * (*cib)) > 16 ? wcap / ((*cob) * (*cib)) : 16;   // ... but <= ~640 workgroups
         if (g > cap) g = cap;
         if (g < 1) g = 1;
         // XCD-aware: workgroup id = group + groups * (co/ci block) and workgroups go round-robin over the 8 XCDs, so
