@@ -315,6 +315,21 @@ def _wgrad(grads, w, g, a, cb, x, **kw):
     grads.put(w, dw)
 
 
+def _on_side(grads, fn, tensors):
+    """Run fn() on the side stream after everything enqueued so far on the current stream (same
+    protocol as _wgrad); `tensors` are its inputs allocated on the main stream."""
+    side = grads.side
+    if side is None:
+        return fn()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        r = fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    return r
+
+
 def _block_backward(rec, dout, grads):
     blk, S = rec["blk"], rec["S"]
     a1, a2, a3, ad = rec["a1"], rec["a2"], rec["a3"], rec["ad"]
@@ -348,10 +363,12 @@ def _block_backward(rec, dout, grads):
         cb2 = _bn_bwd(grads, ps, S, P2, blk.bn2, rec["s2"])
 
     # conv2 (channelwise): fused data + weight backward, relu backward of bn1 in its epilogue
-    g1, dw2, p1 = ops.dw333_bwd(ds, a2, cb2, blk.conv2.weight.data, a1, stride=blk.stride, pre=rec["c1"],
-                                pre_act=ACT_RELU, dw_out=grads.out(blk.conv2.weight))
+    g1, wpart2, p1 = ops.dw333_bwd(ds, a2, cb2, blk.conv2.weight.data, a1, stride=blk.stride, pre=rec["c1"],
+                                   pre_act=ACT_RELU, reduce=False)
     del ds
-    grads.put(blk.conv2.weight, dw2)
+    # the group sum of the 27-tap partials feeds only the optimizer: side stream
+    w2 = blk.conv2.weight
+    grads.put(w2, _on_side(grads, lambda: ops.dw333_bwd_reduce(wpart2, w2.shape, grads.out(w2)), (wpart2,)))
     cb1 = _bn_bwd(grads, p1, S, P1, blk.bn1, rec["s1"])
 
     # conv1 (+ downsample branch)

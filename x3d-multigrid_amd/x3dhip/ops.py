@@ -125,7 +125,9 @@ def dw333_fwd(x, w, stride=1, pre=None, pre_act=ACT_RELU, want_stats=True, out=N
 
 
 def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wpartial=None, partial=None,
-              dw_out=None):
+              dw_out=None, reduce=True):
+    """reduce=False: returns (out, wpartial, partial) and leaves the [N*tiles] -> 1 group sum of the weight-gradient
+    partials to dw333_bwd_reduce (the engine runs it on its side stream: nothing in the backward chain reads dW)."""
     _need_cuda(g, a, cb, w, x, pre)
     L = _lib.lib()
     N, C, T, H, W = x.shape
@@ -137,9 +139,16 @@ def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wp
         partial = _f((N, C, tiles, 2), x)
     check(L.x3d_dw333_bwd(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(x), ptr(pre), pre_act, ptr(o), ptr(wpartial),
                           ptr(partial), N, C, T, H, W, stride, _lib.stream()))
-    # dW[c][27] = sum over (n, tile) groups of the [N][tiles][C][27] partials
+    if not reduce:
+        return o, wpartial, partial
+    return o, dw333_bwd_reduce(wpartial, w.shape, dw_out), partial
+
+
+def dw333_bwd_reduce(wpartial, w_shape, dw_out=None):
+    """dW[c][27] = sum over (n, tile) groups of the [N][tiles][C][27] partials."""
+    N, tiles, C, _ = wpartial.shape
     dw = reduce_partials(wpartial.view(N * tiles, C * 27), C * 27, out=dw_out)
-    return o, dw.view(w.shape), partial
+    return dw.view(w_shape)
 
 
 # ----------------------------------------------------------------------------- stem
