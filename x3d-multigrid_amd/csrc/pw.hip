@@ -1557,21 +1557,193 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad2_kernel(const WgArgs A) {
             }
 }
 
-static bool wgrad2_ok(int P, long long Pin, int Co, int Ci, bool strided) {
-    return !strided && (P % 4 == 0) && (Pin % 4 == 0) && Co >= 64 && Ci >= 48;
+// ---------------------------------------------------------------------------------------
+// Split-bf16 form of the tiled weight-gradient kernel (the default).
+// The fp32 MFMA runs at 1/16 of the bf16 rate on gfx950 and the tiled kernel above spends most of
+// each chunk inside its 128 fp32 MFMAs per wave.  Here both operands are split while they are staged
+// into LDS, v = hi + lo with hi = bf16(v), lo = bf16(v - hi) (16 significant bits), and every
+// 16x16x32 tile product is three bf16 MFMAs, hi*hi + hi*lo + lo*hi, accumulated in fp32: 48 MFMAs of
+// 16 cycles per chunk instead of 128 of 32.  The dropped lo*lo term and the truncation of lo are
+// ~2^-16 relative per product -- about 1e-5 on dW even under heavy cancellation, two orders below the
+// parity tolerance -- and dW feeds only the optimizer, so the error is not amplified by later
+// layers (the same split on the forward / data-gradient GEMMs moves the logits by 2.6e-3:
+// tests/exp_split_precision.py; those stay fp32).
+// LDS image per operand plane: [row][64 voxels] bf16, 144-byte pitch (conflict-free b128 reads).
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+constexpr int W3_LD = 72;          // bf16 elements per LDS row
+
+__device__ __forceinline__ void split_bf16x4(const float (&v)[4], bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(v[e] - (float)h);
+    }
 }
+
+// CO x CI = output tile of a workgroup (dY channels x input channels): 128 x 64 for the wide layers, 64-row and
+// 32-column variants for the narrow ones (stages 1-2) so that padding rows are not staged for nothing.
+template <int CO, int CI>
+__global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
+    constexpr int ND = CO / 16, NX = CI / 16;            // staged float4 slots per thread (dY, input)
+    constexpr int MW = CO / 64, NW = CI / 16;            // 16x16 tiles per wave: MW (dY) x NW (input)
+    __shared__ __attribute__((aligned(16))) __bf16 Dh[CO * W3_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Dlo[CO * W3_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Xh[CI * W3_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Xlo[CI * W3_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int blk = blockIdx.y;
+    const int co0 = (blk / A.cib) * CO, ci0 = (blk % A.cib) * CI;
+    const int P = A.P;
+    const int cps = (P + W2_PT - 1) / W2_PT;            // chunks per sample
+    const int total = A.N * cps;
+
+    const int c4 = (tid & 15) * 4;
+    const int row0 = tid >> 4;                          // staging rows row0 + 16 i
+
+    float4 rg[ND], ra[ND], rx[NX];
+    float k0[ND], k1[ND], k2[ND], sc[NX], sh[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+
+    auto fetch = [&](int c) {
+        const int n = c / cps, pt = (c - n * cps) * W2_PT;
+        const int pc = min(pt + c4, P - 4);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int co = min(co0 + row0 + 16 * i, A.Co - 1);
+            const size_t base = ((size_t)n * A.Co + co) * (size_t)P + pc;
+            rg[i] = *reinterpret_cast<const float4*>(A.g + base);
+            ra[i] = *reinterpret_cast<const float4*>(A.a + base);
+            const float* cb = A.cb + ((size_t)n * A.Co + co) * 3;
+            k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int ci = min(ci0 + row0 + 16 * i, A.Ci - 1);
+            rx[i] = *reinterpret_cast<const float4*>(A.x + ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc);
+            if (A.pre != nullptr) {
+                const float2 p2 = *reinterpret_cast<const float2*>(A.pre + ((size_t)n * A.Ci + ci) * 2);
+                sc[i] = p2.x; sh[i] = p2.y;
+            }
+        }
+    };
+    auto store = [&](int c) {
+        const int n = c / cps, pt = (c - n * cps) * W2_PT;
+        const bool pvv = pt + c4 < P;                   // P % 4 == 0: all four or none
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const bool ok = pvv && (co0 + row0 + 16 * i < A.Co);
+            const float gv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w}, av[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
+            bf16x4 hi, lo;
+            split_bf16x4(v, hi, lo);
+            *reinterpret_cast<bf16x4*>(&Dh[(row0 + 16 * i) * W3_LD + c4]) = hi;
+            *reinterpret_cast<bf16x4*>(&Dlo[(row0 + 16 * i) * W3_LD + c4]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const bool ok = pvv && (ci0 + row0 + 16 * i < A.Ci);
+            float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+            if (A.pre != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(sc[i], v[e], sh[i]), A.pre_act);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            bf16x4 hi, lo;
+            split_bf16x4(v, hi, lo);
+            *reinterpret_cast<bf16x4*>(&Xh[(row0 + 16 * i) * W3_LD + c4]) = hi;
+            *reinterpret_cast<bf16x4*>(&Xlo[(row0 + 16 * i) * W3_LD + c4]) = lo;
+        }
+    };
+
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // 16x16x32 bf16 fragments: lane (r, q) holds k = 8q .. 8q+7 of row r (A: dY channel, B: input channel)
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < W2_PT / 32; ++s) {
+            bf16x8 ah[MW], al[MW], bh[NW], bl[NW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                const int off = ((MW * wave + i) * 16 + r) * W3_LD + s * 32 + 8 * q;
+                ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
+                al[i] = *reinterpret_cast<const bf16x8*>(&Dlo[off]);
+            }
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int off = (j * 16 + r) * W3_LD + s * 32 + 8 * q;
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Xh[off]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
+            }
+#pragma unroll
+            for (int i = 0; i < MW; ++i)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    int c = blockIdx.x;
+    if (c < total) {
+        fetch(c);
+        store(c);
+        __syncthreads();
+        for (; c < total; c += A.groups) {
+            const int cn = c + A.groups;
+            if (cn < total) fetch(cn);
+            compute();
+            __syncthreads();                 // everyone done reading this chunk
+            if (cn < total) { store(cn); __syncthreads(); }
+        }
+    }
+
+    // D[i = co][j = ci]: lane (q, r), reg e -> co = tile*16 + 4q + e, ci = tile*16 + r
+    float* out = A.wpartial + (size_t)blockIdx.x * A.Co * A.Ci;
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int oc = co0 + (MW * wave + i) * 16 + 4 * q + e, ic = ci0 + j * 16 + r;
+                if (oc < A.Co && ic < A.Ci) out[(size_t)oc * A.Ci + ic] = acc[i][j][e];
+            }
+}
+
+static bool wgrad2_ok(int P, long long Pin, int Co, int Ci, bool strided) {
+    return !strided && (P % 4 == 0) && (Pin % 4 == 0);
+}
+// workgroup tile of the split-bf16 kernel for a Co x Ci weight
+static int wg3_co(int Co) { return Co > 64 ? 128 : 64; }
+static int wg3_ci(int Ci) { return Ci > 32 ? 64 : 32; }
 
 // tiled = 1: pw_wgrad2_kernel (cob x cib blocks of 128 x 64), else the direct-load kernel
 static void wgrad_plan(int N, int P, int Co, int Ci, bool dense, int* tiled, int* groups, int* cob, int* cib,
                        int* ct_run, int* it_run) {
     if (wgrad2_ok(P, dense ? P : 1, Co, Ci, !dense)) {
         *tiled = 1;
-        *cob = cdiv(Co, W2_CO); *cib = cdiv(Ci, W2_CI);
+        const bool f32 = getenv("X3D_WGRAD_F32") != nullptr;     // exact fp32-MFMA kernel: fixed 128 x 64 tiles
+        *cob = cdiv(Co, f32 ? W2_CO : wg3_co(Co)); *cib = cdiv(Ci, f32 ? W2_CI : wg3_ci(Ci));
         *ct_run = 8; *it_run = 4;
         const int chunks = N * cdiv(P, W2_PT);
-        static const int cpw = getenv("X3D_WG_CPW") ? atoi(getenv("X3D_WG_CPW")) : 6;
+        static const int cpw = getenv("X3D_WG_CPW") ? atoi(getenv("X3D_WG_CPW")) : 3;
         static const int wcap = getenv("X3D_WG_CAP") ? atoi(getenv("X3D_WG_CAP")) : 640;
-        int g = cdiv(chunks, cpw);                                   // ~6 chunks per workgroup ...
+        int g = cdiv(chunks, cpw);                                   // ~3 chunks per workgroup (two workgroups per CU) ...
         const int cap = wcap / ((*cob) * (*cib)) > 16 ? wcap / ((*cob) * (*cib)) : 16;   // ... but <= ~640 workgroups
         if (g > cap) g = cap;
         if (g < 1) g = 1;
@@ -1715,7 +1887,17 @@ extern "C" int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb
     X3D_CHECK_ARG(A.cob * A.cib <= 65535);
     dim3 grid(A.groups, A.cob * A.cib), block(256);
     if (tiled) {
-        hipLaunchKernelGGL(pw_wgrad2_kernel, grid, block, 0, (hipStream_t)stream, A);
+        // split-bf16 MFMA (3 products, ~1e-5 on dW) by default; X3D_WGRAD_F32 selects the exact fp32-MFMA kernel
+        hipStream_t s3 = (hipStream_t)stream;
+        if (getenv("X3D_WGRAD_F32") != nullptr) {
+            hipLaunchKernelGGL(pw_wgrad2_kernel, grid, block, 0, s3, A);
+        } else if (wg3_co(Cout) == 128) {
+            if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<128, 64>), grid, block, 0, s3, A);
+            else hipLaunchKernelGGL((pw_wgrad3_kernel<128, 32>), grid, block, 0, s3, A);
+        } else {
+            if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<64, 64>), grid, block, 0, s3, A);
+            else hipLaunchKernelGGL((pw_wgrad3_kernel<64, 32>), grid, block, 0, s3, A);
+        }
         X3D_LAUNCH_CHECK();
         return X3D_OK;
     }
