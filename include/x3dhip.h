@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define X3D_ABI_VERSION 1
+#define X3D_ABI_VERSION 2
 
 #define X3D_OK 0
 #define X3D_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
@@ -62,14 +62,17 @@ int x3d_pw_tiles(int N, int K, int M, int P, int dense);
  * as float[N][Cout][x3d_pw_tiles(N,Cin,Cout,Po,strideHW==1)][2] for the BN that follows (x3d.py:51). */
 /* Weight pre-packing for the tiled variant used on large-C layers (K >= 64 and M >= 96, see
  * x3d_pw_wants_packed): x3d_pw_pack writes w[Cout][Cin] into MFMA fragment order
- * (x3d_pw_pack_floats(K, M) floats, zero padded); transposed = 1 packs the backward-data
- * operand (M = Cin, K = Cout).  Weights change every optimizer step: pack once per step.
+ * (x3d_pw_pack_floats(K, M, transposed) floats, zero padded); transposed = 1 packs the backward-data
+ * operand (M = Cin, K = Cout) and appends its split-bf16 image (hi = bf16(w), lo = bf16(w - hi) in
+ * 16x16x32 MFMA fragment order) used by the split-precision data-gradient kernel.
+ * Weights change every optimizer step: pack once per step.
  * Passing NULL for wpacked selects the streaming kernel (same results, same `partial` shape). */
 int x3d_pw_wants_packed(int K, int M);
-size_t x3d_pw_pack_floats(int K, int M);
+size_t x3d_pw_pack_floats(int K, int M, int transposed);
+size_t x3d_pw_pack_items(int K, int M, int transposed);   /* work items (256 per workgroup) of one batched pack job */
 int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int transposed, void* stream);
 /* Batched packing: `jobs` is a device array of records
- *   { const float* w; float* wp; int M, K, ldm, ldk, mtiles, kgroups, wg0, pad; }   (x3d_pw_pack_job_bytes() each;
+ *   { const float* w; float* wp; int M, K, ldm, ldk, mtiles, kgroups, wg0, with_bf16; }   (x3d_pw_pack_job_bytes() each;
  *   A[row][k] = w[row*ldm + k*ldk], mtiles = ceil(M/16), kgroups = ceil(K/16), wg0 = first workgroup of the job)
  * and wg_job[n_workgroups] maps every 256-element workgroup to its job. */
 size_t x3d_pw_pack_job_bytes(void);

@@ -22,7 +22,11 @@ from x3dhip import synthetic  # noqa: E402
 import parity  # noqa: E402
 
 NB = int(sys.argv[1])
-cases = sys.argv[2:] or ["train_M_2x4x32_s1"]
+MODE = "all"                       # all: forward + both backward GEMMs; bwd: backward GEMMs only; wgrad: weight gradient only
+args = sys.argv[2:]
+if args and args[0] in ("all", "bwd", "wgrad", "dgrad"):
+    MODE = args.pop(0)
+cases = args or ["train_M_2x4x32_s1"]
 _conv3d = F.conv3d
 
 
@@ -40,17 +44,24 @@ class PwSplit(torch.autograd.Function):
     def forward(ctx, x, w, stride):
         ctx.save_for_backward(x, w)
         ctx.stride = stride
+        if MODE != "all":
+            return _conv3d(x, w, stride=stride)
         return _conv3d(rnd(x), rnd(w), stride=stride)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        g = rnd(g.contiguous())
+        g = g.contiguous()
+        gr = rnd(g)
         with torch.enable_grad():
+            xe = x.detach().requires_grad_(True)
+            we = w.detach().requires_grad_(True)
+            dx_e, dw_e = torch.autograd.grad(_conv3d(xe, we, stride=ctx.stride), [xe, we], g)
             xr = rnd(x).detach().requires_grad_(True)
             wr = rnd(w).detach().requires_grad_(True)
-            y = _conv3d(xr, wr, stride=ctx.stride)
-            dx, dw = torch.autograd.grad(y, [xr, wr], g)
+            dx_r, dw_r = torch.autograd.grad(_conv3d(xr, wr, stride=ctx.stride), [xr, wr], gr)
+        dx = dx_r if MODE in ("all", "bwd", "dgrad") else dx_e
+        dw = dw_r if MODE in ("all", "bwd", "wgrad") else dw_e
         return dx, dw, None
 
 

@@ -58,6 +58,21 @@ if which.startswith("pw"):
     print("%s fwd(affine+swish): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
     us = t(lambda: ops.pw_fwd(x, w, out=y, wp=wp))
     print("%s fwd(raw): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
+elif which.startswith("dg"):
+    # backward-data of a conv with Cin -> Cout (GEMM K = Cout, M = Cin), swish backward in the epilogue
+    N, Ci, Co, T, H, W = cases["pw" + which[2:]]
+    x = torch.randn(N, Ci, T, H, W, device=dev)
+    g = torch.randn(N, Co, T, H, W, device=dev)
+    a = torch.randn(N, Co, T, H, W, device=dev)
+    cb = torch.rand(N, Co, 3, device=dev)
+    pre = torch.rand(N, Ci, 2, device=dev)
+    w = torch.randn(Co, Ci, device=dev) / Co ** 0.5
+    wpt = ops.pw_pack(w, transposed=True)
+    out = torch.empty_like(x)
+    us = t(lambda: ops.pw_bwd_data(g, a, cb, w, x=x, pre=pre, pre_act=2, out=out, wpt=wpt))
+    fl = 2.0 * N * Ci * Co * T * H * W
+    by = 4.0 * N * (2 * Ci + 2 * Co) * T * H * W
+    print("%s dgrad(bn-bwd in, swish-bwd out): %.1f us  %.2f TFLOP/s  %.0f GB/s" % (which, us, fl / us / 1e6, by / us / 1e3))
 elif which.startswith("wg"):
     N, Ci, Co, T, H, W = cases["pw" + which[2:]]
     x = torch.randn(N, Ci, T, H, W, device=dev)

@@ -505,33 +505,65 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
 constexpr int P2_BN = 64, P2_KC = 64;
 constexpr int P2_NB = P2_KC * P2_BN / 4 / 256;      // activation float4 slots per thread
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+// Packed weight image.
+//   fp32 part (always):   wp[((mt * kgroups + s) * 64 + lane) * 4 + e] = A[16 mt + (lane & 15)][16 s + 4 (lane >> 4) + e]
+//   split-bf16 part (transposed / backward-data packs only), directly behind the fp32 part, for the
+//   16x16x32 bf16 MFMA: two planes (hi = bf16(a), lo = bf16(a - hi)) of
+//                         wq[((mt * kg32 + s) * 64 + lane) * 8 + j] = A[16 mt + (lane & 15)][32 s + 8 (lane >> 4) + j]
+// One work item per fp32 element, then one per bf16 (hi, lo) pair.
+__device__ __forceinline__ void pack_item(int i, const float* __restrict__ w, float* __restrict__ wp, int M, int K, int ldm,
+                                          int ldk, int mtiles, int kgroups, int with_bf16) {
+    const int nf = mtiles * kgroups * 256;
+    if (i < nf) {
+        const int e = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+        const int s = blk % kgroups, mt = blk / kgroups;
+        const int row = 16 * mt + (lane & 15), k = 16 * s + 4 * (lane >> 4) + e;
+        wp[i] = (row < M && k < K) ? w[(size_t)row * ldm + (size_t)k * ldk] : 0.f;
+        return;
+    }
+    if (!with_bf16) return;
+    const int kg32 = (K + 31) / 32;
+    const int nq = mtiles * kg32 * 512;
+    const int t = i - nf;
+    if (t >= nq) return;
+    const int j = t & 7, lane = (t >> 3) & 63, blk = t >> 9;
+    const int s = blk % kg32, mt = blk / kg32;
+    const int row = 16 * mt + (lane & 15), k = 32 * s + 8 * (lane >> 4) + j;
+    const float v = (row < M && k < K) ? w[(size_t)row * ldm + (size_t)k * ldk] : 0.f;
+    const __bf16 h = (__bf16)v;
+    __bf16* wq = reinterpret_cast<__bf16*>(wp + nf);
+    wq[t] = h;
+    wq[nq + t] = (__bf16)(v - (float)h);
+}
+
+static size_t pack_items(int K, int M, int with_bf16) {
+    const size_t mt = cdiv(M, 16);
+    return mt * cdiv(K, 16) * 256 + (with_bf16 ? mt * cdiv(K, 32) * 512 : 0);
+}
+static size_t pack_floats(int K, int M, int with_bf16) {
+    const size_t mt = cdiv(M, 16);
+    return mt * cdiv(K, 16) * 256 + (with_bf16 ? mt * cdiv(K, 32) * 512 : 0);     // two bf16 planes = one float per (hi, lo) pair
+}
+
 __global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, int K,
-                                                      int ldm, int ldk, int mtiles, int kgroups) {
-    // wp[((mt * kgroups + s) * 64 + lane) * 4 + e] = A[16 mt + (lane & 15)][16 s + 4 (lane >> 4) + e]
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= mtiles * kgroups * 256) return;
-    const int e = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
-    const int s = blk % kgroups, mt = blk / kgroups;
-    const int row = 16 * mt + (lane & 15), k = 16 * s + 4 * (lane >> 4) + e;
-    wp[i] = (row < M && k < K) ? w[(size_t)row * ldm + (size_t)k * ldk] : 0.f;
+                                                      int ldm, int ldk, int mtiles, int kgroups, int with_bf16) {
+    pack_item(blockIdx.x * 256 + threadIdx.x, w, wp, M, K, ldm, ldk, mtiles, kgroups, with_bf16);
 }
 
 // Batched form: one launch packs every pointwise weight of the network in both orientations.
 // jobs[] and the workgroup -> job table are built once on the host (x3dhip/engine.py).
 struct PackJob {
     const float* w; float* wp;
-    int M, K, ldm, ldk, mtiles, kgroups, wg0, pad;
+    int M, K, ldm, ldk, mtiles, kgroups, wg0, with_bf16;
 };
 
 __global__ __launch_bounds__(256) void pw_pack_batch_kernel(const PackJob* __restrict__ jobs,
                                                             const int* __restrict__ wg_job) {
     const PackJob J = jobs[wg_job[blockIdx.x]];
-    const int i = (blockIdx.x - J.wg0) * 256 + threadIdx.x;
-    if (i >= J.mtiles * J.kgroups * 256) return;
-    const int e = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
-    const int s = blk % J.kgroups, mt = blk / J.kgroups;
-    const int row = 16 * mt + (lane & 15), k = 16 * s + 4 * (lane >> 4) + e;
-    J.wp[i] = (row < J.M && k < J.K) ? J.w[(size_t)row * J.ldm + (size_t)k * J.ldk] : 0.f;
+    pack_item((blockIdx.x - J.wg0) * 256 + threadIdx.x, J.w, J.wp, J.M, J.K, J.ldm, J.ldk, J.mtiles, J.kgroups, J.with_bf16);
 }
 
 #ifdef X3D_TRACE
@@ -1128,6 +1160,255 @@ __global__ __launch_bounds__(256, 2) void pw4_kernel(const PwArgs A) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// Split-bf16 data-gradient kernel (backward only): pw4_kernel's persistent pipeline with the GEMM
+// on the bf16 matrix rate.  dX = W^T dY with dY = k0*g + k1*a + k2 (BN backward) staged per voxel:
+//   * thread (voxel v = tid & 63, k octet = tid >> 6) loads its 8 channels of g and a (eight dword
+//     loads per tensor, each coalesced over the 64 voxels of the tile), combines, splits the value
+//     into hi = bf16(v), lo = bf16(v - hi) and writes ONE 16-byte row fragment per plane into an LDS
+//     image [voxel][32 channels] -- exactly the B operand of v_mfma_f32_16x16x32_bf16 (lane = voxel,
+//     8 consecutive k), so the transposition costs nothing;
+//   * the A operand comes pre-split and pre-packed (x3d_pw_pack, transposed image);
+//   * each 16x16x32 tile product is hi*hi + hi*lo + lo*hi in fp32: 3 MFMAs of 16 cycles instead
+//     of 8 fp32 MFMAs of 32.
+// Error ~2^-16 per product.  The backward pass is linear in dY with the ReLU masks fixed by the
+// (exact fp32) forward, so this does not amplify: gradients computed this way sit on the fp32
+// noise floor of the reference (tests/exp_split_precision.py, mode "bwd"); the forward GEMMs stay
+// fp32 because there the same split moves the logits by 2.6e-3.
+// Voxel v of a 32-voxel half tile lives in LDS row (v >> 1) + 16 (v & 1): the two 16-column MFMA
+// tiles of a wave then read consecutive rows (conflict-free) and each lane owns voxels 2r, 2r+1.
+// ---------------------------------------------------------------------------------------
+constexpr int P5_BN = 64, P5_KC = 32, P5_LD = 40;       // bf16 elements per LDS row (80 B)
+
+template <int EPI, int U>
+__global__ __launch_bounds__(256, 2) void pw5_kernel(const PwArgs A) {
+    __shared__ __attribute__((aligned(16))) __bf16 Bh[2][P5_BN * P5_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Blo[2][P5_BN * P5_LD];
+    __shared__ float red[(EPI == EPI_PLAIN) ? 4 : 4 * U * 16 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int half = wave & 1, mpar = wave >> 1;
+    const int K = A.K, P = A.P, M = A.M;
+    const int kg16 = (K + 15) / 16, kg32 = (K + 31) / 32, nchunks = kg32;
+    const int mt_run = A.mt_run, mblocks = A.mblocks;
+    const int per_n = ((A.tiles + 7) / 8) * 8 * mblocks;
+    const int items = per_n * A.N;
+    const int mtiles = (M + 15) / 16, mtl = mtiles - 1;
+    const int G = gridDim.x;
+    // split-bf16 planes sit behind the fp32 image of the transposed pack
+    const __bf16* wqh = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
+    const __bf16* wql = wqh + (size_t)mtiles * kg32 * 512;
+
+    auto decode = [&](int it, int& n, int& tile, int& mb) {
+        n = it / per_n;
+        const int rem = it - n * per_n;
+        const int tlo = rem & 7, rest = rem >> 3;
+        mb = rest % mblocks;
+        tile = (rest / mblocks) * 8 + tlo;
+    };
+    auto next_valid = [&](int it, int& n, int& tile, int& mb) {
+        while (it < items) {
+            decode(it, n, tile, mb);
+            if (tile < A.tiles) break;
+            it += G;
+        }
+        return it;
+    };
+
+    // staging role: voxel `lane` of the tile, channels 8 * wave .. 8 * wave + 7 of the chunk
+    const int srow = (lane & 31) >> 1, sodd = lane & 1, shalf = lane >> 5;
+    const int lrow = shalf * 32 + sodd * 16 + srow;                 // LDS row of this thread's voxel
+    float rg[8], ra[8], cf[8][3];
+    bool okv;
+    int kbase;
+
+    auto prefetch = [&](int n, int tile, int c) {
+        const int p = tile * P5_BN + lane;
+        okv = p < P;
+        const int pc = okv ? p : 0;
+        kbase = c * P5_KC + 8 * wave;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kc = min(kbase + j, K - 1);                    // wave-uniform row
+            const size_t rowi = (size_t)n * K + kc;
+            rg[j] = A.x[rowi * (size_t)P + pc];
+            ra[j] = A.a[rowi * (size_t)P + pc];
+            const float* pc3 = A.cin + rowi * 3;
+            cf[j][0] = pc3[0]; cf[j][1] = pc3[1]; cf[j][2] = pc3[2];
+        }
+    };
+
+    auto store = [&](int buf) {
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = fmaf(cf[j][0], rg[j], fmaf(cf[j][1], ra[j], cf[j][2]));
+            v = (okv && kbase + j < K) ? v : 0.f;
+            const __bf16 h = (__bf16)v;
+            hi[j] = h;
+            lo[j] = (__bf16)(v - (float)h);
+        }
+        *reinterpret_cast<bf16x8*>(&Bh[buf][lrow * P5_LD + 8 * wave]) = hi;
+        *reinterpret_cast<bf16x8*>(&Blo[buf][lrow * P5_LD + 8 * wave]) = lo;
+    };
+
+    auto fetch_a = [&](int mb, int c, bf16x8 (&dh)[U], bf16x8 (&dl)[U]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int mt = min(mb * mt_run + mpar + 2 * j, mtl);             // clamped: duplicates are never stored
+            const size_t off = (((size_t)mt * kg32 + c) * 64 + lane) * 8;
+            dh[j] = *reinterpret_cast<const bf16x8*>(wqh + off);
+            dl[j] = *reinterpret_cast<const bf16x8*>(wql + off);
+        }
+    };
+
+    f32x4 acc[U][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < U; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    };
+
+    auto compute = [&](int buf, const bf16x8 (&ah)[U], const bf16x8 (&al)[U]) {
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int off = (half * 32 + h2 * 16 + r) * P5_LD + 8 * q;      // column r of tile h2 = voxel 32 half + 2 r + h2
+            bh[h2] = *reinterpret_cast<const bf16x8*>(&Bh[buf][off]);
+            bl[h2] = *reinterpret_cast<const bf16x8*>(&Blo[buf][off]);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], bh[h2], acc[j][h2], 0, 0, 0);
+                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bl[h2], acc[j][h2], 0, 0, 0);
+                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bh[h2], acc[j][h2], 0, 0, 0);
+            }
+    };
+
+    const bool has_add = A.addend != nullptr;
+    const bool add_s2 = has_add && A.addend_stride == 2;
+    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+
+    // identical to pw4_kernel's epilogue (lane: rows 4q + e of each unit, voxels 32 half + 2 r, + 1)
+    auto epilogue = [&](int n, int tile, int mb) {
+        const int m0 = mb * mt_run * 16;
+        const int bm = min(mt_run * 16, M - m0);
+        const int pl = tile * P5_BN + 32 * half + 2 * r;
+        const bool pv = pl < P;
+        const int pc = pv ? pl : 0;
+        int aoff[2] = {pc, pc + 1};
+        bool av[2] = {has_add && pv, has_add && pv};
+        if (add_s2) {
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int p = pc + j2;
+                const int hw = A.H * A.W;
+                const int t = p / hw, rem = p - t * hw;
+                const int h = rem / A.W, w = rem - h * A.W;
+                const bool even = !(h & 1) && !(w & 1);
+                av[j2] = av[j2] && even;
+                aoff[j2] = even ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int lt = mpar + 2 * j;
+            float xv[4][2], adv[4][2], esc[4], esh[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = lt * 16 + 4 * q + e;
+                const size_t mrow = (size_t)n * M + m0 + ((lt < mt_run && ml < bm) ? ml : 0);
+                if (EPI == EPI_ACTBWD) {
+                    const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
+                    esc[e] = c2.x; esh[e] = c2.y;
+                    const float2 t2 = *reinterpret_cast<const float2*>(A.ex + mrow * (size_t)P + pc);
+                    xv[e][0] = t2.x; xv[e][1] = t2.y;
+                }
+                if (has_add) {
+                    const float* pa = A.addend + mrow * (size_t)addP;
+                    if (!add_s2) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(pa + pc);
+                        adv[e][0] = t2.x; adv[e][1] = t2.y;
+                    } else {
+                        adv[e][0] = pa[aoff[0]]; adv[e][1] = pa[aoff[1]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = lt * 16 + 4 * q + e;
+                const bool mv = lt < mt_run && ml < bm;
+                float v[2] = {acc[j][0][e], acc[j][1][e]};
+                float s1 = 0.f, s2 = 0.f;
+                if (has_add) { v[0] += av[0] ? adv[e][0] : 0.f; v[1] += av[1] ? adv[e][1] : 0.f; }
+                if (EPI == EPI_ACTBWD) {
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const float xj = pv ? xv[e][j2] : 0.f;
+                        v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                        s1 += v[j2];
+                        s2 = fmaf(v[j2], xj, s2);
+                    }
+                }
+                if (mv && pv)
+                    *reinterpret_cast<float2*>(A.y + ((size_t)n * M + m0 + ml) * (size_t)P + pl) = make_float2(v[0], v[1]);
+                if (EPI != EPI_PLAIN) {
+                    s1 = row16_sum(s1);
+                    s2 = row16_sum(s2);
+                    if (r == 0) {
+                        red[((wave * U + j) * 16 + 4 * q + e) * 2] = mv ? s1 : 0.f;
+                        red[((wave * U + j) * 16 + 4 * q + e) * 2 + 1] = mv ? s2 : 0.f;
+                    }
+                }
+            }
+        }
+        if (EPI != EPI_PLAIN && A.partial != nullptr) {
+            __syncthreads();
+            for (int idx = tid; idx < bm * 2; idx += 256) {
+                const int ml = idx >> 1, which = idx & 1;
+                const int lt = ml >> 4, wv = (lt & 1) * 2, j = lt >> 1;
+                const float s = red[(((wv)*U + j) * 16 + (ml & 15)) * 2 + which] +
+                                red[(((wv + 1) * U + j) * 16 + (ml & 15)) * 2 + which];
+                A.partial[(((size_t)n * M + (m0 + ml)) * A.tiles + tile) * 2 + which] = s;
+            }
+        }
+    };
+
+    // ---------------------------------- flat pipeline (as pw4_kernel) ----------------------------------
+    int n = 0, tile = 0, mb = 0;
+    int it = next_valid(blockIdx.x, n, tile, mb);
+    if (it >= items) return;
+    int pn = n, ptile = tile, pmb = mb, pit = it, pc_ = 0;
+    auto advance = [&]() {
+        if (++pc_ == nchunks) { pc_ = 0; pit = next_valid(pit + G, pn, ptile, pmb); }
+    };
+    bf16x8 a0h[U], a0l[U], a1h[U], a1l[U];
+    prefetch(pn, ptile, 0);
+    fetch_a(pmb, 0, a0h, a0l);
+    advance();
+    zero_acc();
+    int c = 0;
+    for (;;) {
+        store(0);
+        __syncthreads();
+        bool more = pit < items;
+        if (more) { prefetch(pn, ptile, pc_); fetch_a(pmb, pc_, a1h, a1l); advance(); }
+        compute(0, a0h, a0l);
+        if (++c == nchunks) { epilogue(n, tile, mb); zero_acc(); c = 0; it = next_valid(it + G, n, tile, mb); }
+        if (!more) break;
+        store(1);
+        __syncthreads();
+        more = pit < items;
+        if (more) { prefetch(pn, ptile, pc_); fetch_a(pmb, pc_, a0h, a0l); advance(); }
+        compute(1, a1h, a1l);
+        if (++c == nchunks) { epilogue(n, tile, mb); zero_acc(); c = 0; it = next_valid(it + G, n, tile, mb); }
+        if (!more) break;
+    }
+}
+
 // One decision function for kernel variant and tile count (the caller sizes `partial` with it).
 // variant: 0 = streaming NT=4, 1 = streaming NT=1, 2 = LDS-tiled (pw2)
 static void pw_plan(int N, int K, int M, int P, bool dense, int* variant, int* tiles, int* mblocks, int* mt_run) {
@@ -1182,6 +1463,15 @@ int launch_pw(PwArgs& A, hipStream_t s) {
         const int items = cdiv(A.tiles, 8) * 8 * A.mblocks * A.N;
         dim3 pgrid(min(items, 512));            // two resident workgroups per CU walk the item list
         const int U = cdiv(A.mt_run, 2);
+        if (IN == IN_BNBWD && EPI != EPI_STATS && getenv("X3D_DGRAD_F32") == nullptr) {
+            // backward-data: split-bf16 MFMA (the transposed pack carries the bf16 planes)
+            constexpr int E5 = (EPI == EPI_STATS) ? EPI_PLAIN : EPI;
+            if (U <= 2) hipLaunchKernelGGL((pw5_kernel<E5, 2>), pgrid, block, 0, s, A);
+            else if (U == 3) hipLaunchKernelGGL((pw5_kernel<E5, 3>), pgrid, block, 0, s, A);
+            else hipLaunchKernelGGL((pw5_kernel<E5, 4>), pgrid, block, 0, s, A);
+            X3D_LAUNCH_CHECK();
+            return X3D_OK;
+        }
         if (U <= 2) hipLaunchKernelGGL((pw4_kernel<IN, EPI, 2>), pgrid, block, 0, s, A);
         else if (U == 3) hipLaunchKernelGGL((pw4_kernel<IN, EPI, 3>), pgrid, block, 0, s, A);
         else hipLaunchKernelGGL((pw4_kernel<IN, EPI, 4>), pgrid, block, 0, s, A);
@@ -1570,8 +1860,6 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad2_kernel(const WgArgs A) {
 // tests/exp_split_precision.py; those stay fp32).
 // LDS image per operand plane: [row][64 voxels] bf16, 144-byte pitch (conflict-free b128 reads).
 // ---------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 constexpr int W3_LD = 72;          // bf16 elements per LDS row
 
 __device__ __forceinline__ void split_bf16x4(const float (&v)[4], bf16x4& hi, bf16x4& lo) {
@@ -1799,17 +2087,18 @@ extern "C" int x3d_pw_tiles(int N, int K, int M, int P, int dense) {
 
 extern "C" int x3d_pw_wants_packed(int K, int M) { (void)K; (void)M; return 1; }
 
-extern "C" size_t x3d_pw_pack_floats(int K, int M) { return (size_t)cdiv(M, 16) * cdiv(K, 16) * 256; }
+extern "C" size_t x3d_pw_pack_floats(int K, int M, int transposed) { return pack_floats(K, M, transposed); }
+extern "C" size_t x3d_pw_pack_items(int K, int M, int transposed) { return pack_items(K, M, transposed); }
 
 extern "C" int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int transposed, void* stream) {
     X3D_CHECK_ARG(w && wp && Cout > 0 && Cin > 0);
     // forward:    A[row = co][k = ci] = w[co*Cin + ci]   (M = Cout, K = Cin)
-    // transposed: A[row = ci][k = co] = w[co*Cin + ci]   (M = Cin,  K = Cout)   (backward-data)
+    // transposed: A[row = ci][k = co] = w[co*Cin + ci]   (M = Cin,  K = Cout)   (backward-data; + split-bf16 planes)
     const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
     const int ldm = transposed ? 1 : Cin, ldk = transposed ? Cin : 1;
     const int mtiles = cdiv(M, 16), kgroups = cdiv(K, 16);
-    hipLaunchKernelGGL(pw_pack_kernel, dim3(cdiv(mtiles * kgroups * 256, 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
-                       M, K, ldm, ldk, mtiles, kgroups);
+    hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)cdiv((int)pack_items(K, M, transposed), 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, wp, M, K, ldm, ldk, mtiles, kgroups, transposed ? 1 : 0);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

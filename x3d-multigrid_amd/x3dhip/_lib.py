@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx3dhip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 
@@ -26,7 +26,8 @@ SIGNATURES = {
     "x3d_last_error": (ctypes.c_char_p, []),
     "x3d_pw_tiles": (_I, [_I, _I, _I, _I, _I]),
     "x3d_pw_wants_packed": (_I, [_I, _I]),
-    "x3d_pw_pack_floats": (_Z, [_I, _I]),
+    "x3d_pw_pack_floats": (_Z, [_I, _I, _I]),
+    "x3d_pw_pack_items": (_Z, [_I, _I, _I]),
     "x3d_pw_pack": (_I, [_P, _P, _I, _I, _I, _P]),
     "x3d_pw_pack_job_bytes": (_Z, []),
     "x3d_pw_pack_batch": (_I, [_P, _P, _I, _P]),

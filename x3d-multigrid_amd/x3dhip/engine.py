@@ -63,14 +63,15 @@ class WeightPacks:
         dev = convs[0].device
         assert L.x3d_pw_pack_job_bytes() == 48
         dt = np.dtype([("w", "<u8"), ("wp", "<u8"), ("M", "<i4"), ("K", "<i4"), ("ldm", "<i4"), ("ldk", "<i4"),
-                       ("mtiles", "<i4"), ("kgroups", "<i4"), ("wg0", "<i4"), ("pad", "<i4")])
-        sizes, metas = [], []
+                       ("mtiles", "<i4"), ("kgroups", "<i4"), ("wg0", "<i4"), ("with_bf16", "<i4")])
+        sizes, metas, items = [], [], []
         for w in convs:
             co, ci = w.shape[0], w.shape[1]
             for transposed in (False, True):
                 M, K = (ci, co) if transposed else (co, ci)
-                n = int(L.x3d_pw_pack_floats(K, M))
+                n = int(L.x3d_pw_pack_floats(K, M, 1 if transposed else 0))
                 sizes.append(n)
+                items.append(int(L.x3d_pw_pack_items(K, M, 1 if transposed else 0)))
                 metas.append((w, transposed, M, K, 1 if transposed else ci, ci if transposed else 1))
         self.buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
         jobs = np.zeros(len(metas), dtype=dt)
@@ -79,8 +80,9 @@ class WeightPacks:
         for j, ((w, transposed, M, K, ldm, ldk), n) in enumerate(zip(metas, sizes)):
             view = self.buf[off:off + n]
             self.views[(id(w), transposed)] = view
-            nwg = (n + 255) // 256
-            jobs[j] = (w.data_ptr(), view.data_ptr(), M, K, ldm, ldk, (M + 15) // 16, (K + 15) // 16, wg, 0)
+            nwg = (items[j] + 255) // 256
+            jobs[j] = (w.data_ptr(), view.data_ptr(), M, K, ldm, ldk, (M + 15) // 16, (K + 15) // 16, wg,
+                       1 if transposed else 0)
             wg_job += [j] * nwg
             self.ptrs.append(w.data_ptr())
             off += n

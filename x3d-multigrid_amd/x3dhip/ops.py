@@ -53,7 +53,7 @@ def pw_pack(w, transposed=False):
     K, M = (Cout, Cin) if transposed else (Cin, Cout)
     if not L.x3d_pw_wants_packed(K, M):
         return None
-    wp = _f((L.x3d_pw_pack_floats(K, M),), w)
+    wp = _f((L.x3d_pw_pack_floats(K, M, 1 if transposed else 0),), w)
     check(L.x3d_pw_pack(ptr(w), ptr(wp), Cout, Cin, 1 if transposed else 0, _lib.stream()))
     return wp
 
