@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
 // Persistent, software-pipelined form of the tiled kernel for dense inputs with P % 4 == 0.
 // pw2_kernel's workgroups all start together and run load -> MFMA -> store in lock step, so
 // the memory phases and the MFMA phase never overlap (per-workgroup timeline:
-// profiles/r01/pw2_timeline.txt).  Here a workgroup walks a strided list of work items
+// profiles/r01/timelines.txt).  Here a workgroup walks a strided list of work items
 // (sample, 64-voxel tile, M block) as ONE flat sequence of 32-channel chunks:
 //   * the global reads of chunk g+1 (activations, per-channel coefficients, packed weight
 //     fragments) are issued before the MFMAs of chunk g and written to the other LDS buffer
