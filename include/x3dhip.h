@@ -231,6 +231,28 @@ int x3d_bn_relu_pool_bwd(const float* a5, const float* c5, const float* dpooled,
 int x3d_sgd_fused(float* w, const float* g, float* m, size_t n, float lr, float momentum,
                   float weight_decay, float grad_scale, int first, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * GPU-side clip input pipeline.  Replaces, per sample, the CPU work of
+ * kinetics_multigrid.py:240-253 on decoded uint8 frames: frame selection (TemporalRandomCrop,
+ * transforms/temporal_transforms.py:94-117 -- indices computed by the host), crop + PIL bilinear
+ * resize (MultiScaleRandomCropMultigrid, transforms/spatial_transforms.py:480-495), horizontal flip
+ * (:334-346), ToTensor(255) + Normalize (:44-83,106-116), stack/permute to [3][T][S][S].
+ * Bit-exact with Pillow's 8-bit bilinear resample given the host-built coefficient table
+ * (x3dhip/clip_input.py:resize_coeffs = Resample.c precompute_coeffs + normalize_coeffs_8bpc).
+ * `jobs`: device array of X3DClipJob, one per sample; all pointers are device pointers. */
+typedef struct {
+    const unsigned char* src;   /* [Tsrc][Hs][Ws][3] decoded frames */
+    unsigned char* tmp;         /* scratch [T][crop][out][3] */
+    float* dst;                 /* [3][T][out][out]: the sample's slice of the NCTHW batch */
+    const int* kk;              /* [out][ksize] 22-bit fixed-point coefficients */
+    const int* bounds;          /* [out][2] (first input index, tap count) */
+    const int* frames;          /* [T] 0-based source frame per output frame */
+    int Hs, Ws, x1, y1, crop, out, ksize, T, flip, pad;
+} X3DClipJob;
+size_t x3d_clip_job_bytes(void);
+int x3d_clip_preprocess(const void* jobs, int njobs, int max_T, int max_crop, int max_out,
+                        const float* mean3, const float* std3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

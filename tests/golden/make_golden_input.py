@@ -1,0 +1,53 @@
+"""Golden vectors of the per-clip input pipeline, produced by the REFERENCE's own transform classes
+(/root/reference/transforms/{spatial,temporal}_transforms.py, which call PIL) on synthetic uint8 frames.
+Run in the build container only:   python tests/golden/make_golden_input.py
+Fixtures are data only: the synthetic frames' seed, the random parameters the reference drew, the clip it produced.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "x3d-multigrid_amd"))
+from x3dhip.synthetic import synthetic_frames_u8 as frames_u8  # noqa: E402
+sys.path.insert(0, "/root/reference")
+from transforms import spatial_transforms as st  # noqa: E402
+from transforms import temporal_transforms as tt  # noqa: E402
+
+MEAN = [110.63666788 / 255, 103.16065604 / 255, 96.29023126 / 255]
+STD = [38.7568578 / 255, 37.88248729 / 255, 40.02898126 / 255]
+
+
+def case(name, seed, n_frames, h, w, crop_size, c_size, num_frames, gamma_tau, sample_duration):
+    random.seed(seed)
+    fr = frames_u8(n_frames, h, w, seed)
+    resize_size = {'S': [180., 225.], 'M': [256., 320.], 'XL': [360., 450.]}['M']       # train...:54
+    spatial = st.Compose([st.MultiScaleRandomCropMultigrid([crop_size / i for i in resize_size], crop_size),
+                          st.RandomHorizontalFlip(), st.ToTensor(255), st.Normalize(MEAN, STD)])          # :70-73
+    temporal = tt.TemporalRandomCrop(num_frames, gamma_tau)                                                # :74
+    frame_indices = list(range(1, n_frames + 1))
+    t_stride = random.randint(1, max(1, num_frames // sample_duration))                                    # kinetics_multigrid.py:245
+    idx = temporal(frame_indices, t_stride, sample_duration)
+    spatial.randomize_parameters(c_size)
+    crop_t, flip_t = spatial.transforms[0], spatial.transforms[1]
+    clip = [spatial(Image.fromarray(fr[i - 1])) for i in idx]
+    clip = torch.stack(clip, 0).permute(1, 0, 2, 3).numpy()
+    np.savez_compressed(os.path.join(HERE, "input_%s.npz" % name), frames_seed=seed, n_frames=n_frames, h=h, w=w,
+                        frame_idx=np.array(idx), begin_index=idx[0] - 1, t_stride=t_stride, num_frames=num_frames,
+                        gamma_tau=gamma_tau, sample_duration=sample_duration, c_size=c_size, scale=crop_t.scale,
+                        tl_x=crop_t.tl_x, tl_y=crop_t.tl_y, p=flip_t.p, clip=clip.astype(np.float32))
+    print(name, "idx", idx, "scale %.4f flip %s" % (crop_t.scale, flip_t.p < 0.5), clip.shape)
+
+
+if __name__ == "__main__":
+    # (name, seed, source frames, H, W, crop_size of the schedule, c_size of this step, num_frames, gamma_tau, sample_duration)
+    # sample_duration is the dataset's num_frames (= 16 * gamma_tau) divided by the long-cycle factor (kinetics_multigrid.py:205-209)
+    case("a_96x128_to32", 1, 100, 96, 128, 224, 32, 16 * 5, 5, 80)       # 16 frames
+    case("b_120x90_to47", 2, 90, 120, 90, 224, 47, 16 * 5, 5, 40)        # 8 frames, t_stride in {1, 2}
+    case("c_64x64_to79", 3, 120, 64, 64, 224, 79, 16 * 5, 5, 20)         # 4 frames, upscale (crop < output)
+    case("d_240x320_to112", 4, 30, 240, 320, 224, 112, 16 * 5, 5, 80)    # short video: indices are looped
+    case("e_72x100_to56", 7, 85, 72, 100, 224, 56, 16 * 5, 5, 40)

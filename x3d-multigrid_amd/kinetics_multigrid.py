@@ -41,3 +41,43 @@ def device_batch(B, T, H, n_classes, device, generator=None):
     x = torch.randn(B, 3, T, H, H, device=device, generator=generator)
     y = torch.randint(0, n_classes, (B, 1), device=device, generator=generator)
     return x, y
+
+
+class DeviceVideoKinetics:
+    """Kinetics.__getitem__'s protocol (kinetics_multigrid.py:214-259) over decoded uint8 videos that are already
+    resident in HBM: the per-sample random draws happen on the host in the reference's order
+    (x3dhip.clip_input.draw_clip_params), and crop + PIL-bilinear resize + flip + ToTensor + Normalize + the
+    [3,T,H,W] stacking run as two HIP kernels for the whole batch (x3dhip.clip_input.ClipPreprocessor).
+
+    videos: list of uint8 CUDA tensors [n_frames, H, W, 3]; labels: list of ints.  ``batch(indices, iteration,
+    long_cycle_state)`` returns (clips float32 [B,3,T,S,S], labels int64 [B,1], long_cycle_state, stats)."""
+
+    RESIZE = {'S': [180., 225.], 'M': [256., 320.], 'XL': [360., 450.]}      # train_x3d_kinetics_multigrid.py:54
+
+    def __init__(self, videos, labels, sample_duration=80, gamma_tau=5, crop_size=224, x3d_version='M', rng=None):
+        import random
+        from x3dhip.clip_input import ClipPreprocessor
+        self.videos, self.labels = videos, labels
+        self.sample_duration, self.gamma_tau, self.crop_size = sample_duration, gamma_tau, crop_size
+        self.long_cycles = long_cycle_shapes(sample_duration, crop_size)
+        self.scales = [crop_size / i for i in self.RESIZE[x3d_version]]       # train...:70
+        self.rng = rng if rng is not None else random
+        self.pre = ClipPreprocessor(videos[0].device)
+
+    def __len__(self):
+        return len(self.videos)
+
+    def batch(self, indices, iteration, long_cycle_state, out=None):
+        from x3dhip.clip_input import draw_clip_params
+        frames, crop = self.long_cycles[long_cycle_state]
+        stats = (frames, crop // 2, int(crop / 2 ** 0.5), crop)
+        T, S = step_clip_shape(long_cycle_state, iteration, self.sample_duration, self.gamma_tau, self.crop_size)
+        samples = []
+        for i in indices:
+            v = self.videos[i]
+            p = draw_clip_params(v.shape[0], v.shape[2], v.shape[1], self.scales, S, self.sample_duration, self.gamma_tau,
+                                 frames, rng=self.rng)
+            samples.append((v, p))
+        clips = self.pre(samples, out=out)
+        y = torch.tensor([[self.labels[i]] for i in indices], dtype=torch.int64, device=clips.device)
+        return clips, y, long_cycle_state, stats

@@ -23,6 +23,8 @@ _Z = ctypes.c_size_t
 # tests/test_abi.py checks the two against each other.
 SIGNATURES = {
     "x3d_abi_version": (_I, []),
+    "x3d_clip_job_bytes": (_Z, []),
+    "x3d_clip_preprocess": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "x3d_last_error": (ctypes.c_char_p, []),
     "x3d_pw_tiles": (_I, [_I, _I, _I, _I, _I]),
     "x3d_pw_wants_packed": (_I, [_I, _I]),

@@ -78,3 +78,17 @@ def gradient_sketch(grads, nproj=16, seed=7):
         r = _rng("sketch:" + name, seed).standard_normal((nproj, v.size), dtype=np.float32)
         acc += r.astype(np.float64) @ v
     return acc
+
+
+def synthetic_frames_u8(n, h, w, seed=0):
+    """Deterministic synthetic "decoded video": uint8 [n][h][w][3] (low-frequency pattern + noise).  numpy only, so the
+    golden generator, the CPU tests and the GPU tests regenerate identical frames from (n, h, w, seed)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = np.zeros((n, h, w, 3), dtype=np.uint8)
+    for t in range(n):
+        for c in range(3):
+            base = 127 + 90 * np.sin(0.07 * xx * (c + 1) + 0.3 * t) * np.cos(0.05 * yy + 0.2 * c)
+            out[t, :, :, c] = np.clip(base + rng.normal(0, 25, size=(h, w)), 0, 255).astype(np.uint8)
+    return out
