@@ -78,3 +78,46 @@ def test_graph_replay_equals_eager_and_torch_sgd():
     (l0, f0, _, _), (l2, f2, _, _) = [_run_mode(m, 2, sd, x, y, dev) for m in ("eager", "torch")]
     assert abs(l0 - l2) < 1e-3 * abs(l0)
     assert ((f0 - f2).norm() / f2.norm()).item() < 1e-3     # update size is ~0.15 relative per step
+
+
+def test_validate_matches_oracle_multi_crop():
+    """validate(): aggregate split-BN stats, eval forward of b*n temporal crops, crop-averaged softmax / logits
+    (train_x3d_kinetics_multigrid.py:203-206, 239-266) against the same protocol evaluated with the CPU oracle."""
+    import torch.nn.functional as F
+    import x3d as resnet_x3d
+    import train_x3d_kinetics_multigrid as tr
+    from oracle import x3d_oracle as xo
+    from x3dhip import synthetic
+    dev = torch.device("cuda:0")
+    S = 2
+    sd = synthetic.procedural_state_dict(xo.state_template("M", 400, S), 3)
+    # make the split running statistics differ per split so that the aggregation matters
+    for k in list(sd):
+        if "split_bn.running_mean" in k:
+            sd[k] = sd[k] + 0.05 * torch.randn(sd[k].shape, generator=torch.Generator().manual_seed(len(k)))
+        if "split_bn.running_var" in k:
+            sd[k] = sd[k] * (1 + 0.2 * torch.rand(sd[k].shape, generator=torch.Generator().manual_seed(len(k) + 1)))
+    model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.5, base_bn_splits=S)
+    model.load_state_dict(sd)
+    model.to(dev)
+    b, n, T, H = 2, 3, 4, 48
+    batches = []
+    for i in range(2):
+        x = synthetic.synthetic_clips(b * n, T, H, H, seed=50 + i).view(b, n, 3, T, H, H)
+        y = synthetic.synthetic_labels(b, seed=60 + i).view(b)
+        batches.append((x, y))
+    loss, acc, seen = tr.validate(model, [(x.to(dev), y.to(dev)) for x, y in batches])
+    assert seen == 2 * b and not model.training
+    # oracle: aggregate, eval forward, same reductions
+    sd2 = dict(sd)
+    sd2.update(xo.aggregate_sub_bn(sd, S))
+    tot, corr = 0.0, 0
+    for x, y in batches:
+        lg = xo.forward(x.view(b * n, 3, T, H, H), sd2, "M", S, training=False)         # [b*n, 400, 1]
+        lg = lg.view(b, n, 400, 1)
+        sm = F.softmax(lg, dim=2).mean(1)
+        lgm = lg.mean(1)
+        tot += float(F.cross_entropy(lgm, y.view(b, 1)))
+        corr += int((sm.max(1)[1] == y.view(b, 1)).sum())
+    assert abs(loss - tot / 2) / (tot / 2) < 1e-3
+    assert acc == corr / (2 * b)

@@ -115,6 +115,32 @@ def print_stats(long_ind, batch_size, stats, gamma_tau, bn_splits, lr):
             lr, stats[0], gamma_tau, bs * 4, bs * 2, bs, stats[1], stats[2], stats[3], bn_splits, long_ind), flush=True)
 
 
+def validate(model, batches):
+    """Validation phase of the reference loop (train_x3d_kinetics_multigrid.py:203-206, 239-266, 288-292):
+    eval mode, `aggregate_sub_bn_stats()` first, no gradients; every batch is [b, n, 3, T, H, W] with n temporal crops
+    per video, run as b*n clips; prediction = argmax of the crop-averaged SOFTMAX, loss = cross entropy of the
+    crop-averaged LOGITS against the label.  Returns (mean loss per batch, top-1 accuracy, videos seen).
+    The model is left in eval mode (the caller switches back with model.train(True), as the reference does)."""
+    import torch.nn.functional as F
+    model.train(False)
+    model.aggregate_sub_bn_stats()
+    tot_cls_loss, tot_corr, tot_dat, num_iter = 0.0, 0.0, 0, 0
+    with torch.no_grad():
+        for inputs, labels in batches:
+            num_iter += 1
+            b, n, c, t, h, w = inputs.shape
+            logits = model(inputs.view(b * n, c, t, h, w))                 # [b*n, classes, 1]
+            logits = logits.view(b, n, logits.shape[1], 1)
+            logits_sm = torch.mean(F.softmax(logits, dim=2), 1)
+            logits = torch.mean(logits, 1)
+            preds = torch.max(logits_sm, 1)[1]                             # [b, 1]
+            labels = labels.view(b, 1)
+            tot_cls_loss += float(F.cross_entropy(logits, labels))
+            tot_corr += float(torch.sum(preds == labels))
+            tot_dat += b
+    return tot_cls_loss / max(num_iter, 1), tot_corr / max(tot_dat, 1), tot_dat
+
+
 def run(init_lr=INIT_LR, warmup_steps=8000, max_epochs=120, batch_size=BS * BS_UPSCALE, steps=0, max_steps_run=None,
         iterations_per_epoch=None, load_ckpt=None, save_model='models/x3d_multigrid_kinetics_rgb_sgd_',
         save_every=4000, use_graph=True, x3d_version=X3D_VERSION, log_every=20):
