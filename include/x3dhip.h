@@ -219,12 +219,14 @@ int x3d_bn_add_relu_bwd(const float* dout, const float* out, const float* a3, co
                         float* g, float* partial, float* partial_d,
                         int N, int C, int P, void* stream);
 
-/* Head pooling (x3d.py:328-331): pooled[n][c] = mean_p relu(c5*a5).  Backward:
- * g = dpooled/P * (c5*a5 > 0), partial {sum g, sum g*a5}. */
+/* Head pooling (x3d.py:328-331): pooled[n][c][s] = mean over segment s of relu(c5*a5); segs = 1 is
+ * AdaptiveAvgPool3d((1,1,1)) (task 'class', x3d.py:239), segs = T is AdaptiveAvgPool3d((None,1,1)) (task 'loc',
+ * x3d.py:241; segment = one T plane, P % segs == 0).  Backward: g = dpooled[n][c][s]/(P/segs) * (c5*a5 > 0),
+ * partial {sum g, sum g*a5}. */
 int x3d_bn_relu_pool_fwd(const float* a5, const float* c5, float* pooled,
-                         int N, int C, int P, void* stream);
+                         int N, int C, int P, int segs, void* stream);
 int x3d_bn_relu_pool_bwd(const float* a5, const float* c5, const float* dpooled,
-                         float* g, float* partial, int N, int C, int P, void* stream);
+                         float* g, float* partial, int N, int C, int P, int segs, void* stream);
 
 /* Fused SGD (torch.optim.SGD, train_x3d_kinetics_multigrid.py:183): g += wd*w;
  * m = first ? g : mu*m + g; w -= lr*m.  grad_scale multiplies g first (1/world_size). */

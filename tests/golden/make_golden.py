@@ -59,7 +59,7 @@ def _grad_record(net, out, tag):
     return grads
 
 
-def train_case(ref, version, B, T, H, splits, seed=0):
+def train_case(ref, version, B, T, H, splits, seed=0, task="class"):
     """One training step of the reference in fp32 (the parity target) and in fp64 (the
     same reference code after .double(): the exact-arithmetic value, which measures how
     much of an fp32 discrepancy is the reference's own rounding noise)."""
@@ -69,15 +69,17 @@ def train_case(ref, version, B, T, H, splits, seed=0):
     g32 = None
     for tag, dt in (("", torch.float32), ("64", torch.float64)):
         torch.manual_seed(0)
-        net = ref.generate_model(version, n_classes=400, dropout=0.0, base_bn_splits=splits)
+        net = ref.generate_model(version, n_classes=400, dropout=0.0, base_bn_splits=splits, task=task)
         sd = synthetic.procedural_state_dict(net.state_dict(), seed)
         net.load_state_dict(sd)
         net = net.to(dt)
         net.train(True)
         logits = net(x.to(dt))
-        loss = torch.nn.CrossEntropyLoss()(logits, y)
+        # task='loc' (x3d.py:340-343): per-frame logits [B, C, T]; the same label on every frame gives a scalar loss
+        # that exercises the whole per-frame head (the Charades losses of train_x3d_charades_loc.py are out of scope)
+        loss = torch.nn.CrossEntropyLoss()(logits, y if task == "class" else y.expand(B, logits.shape[2]))
         loss.backward()
-        out["logits" + tag] = logits.detach().numpy()[:, :, 0]
+        out["logits" + tag] = logits.detach().numpy()[:, :, 0] if task == "class" else logits.detach().numpy()
         out["loss" + tag] = np.float64(loss.item())
         grads = _grad_record(net, out, tag)
         if tag == "":
@@ -110,7 +112,7 @@ def train_case(ref, version, B, T, H, splits, seed=0):
                 out["agg_rv/" + p] = st[p + ".bn.running_var"].numpy()
             out["n_agg"] = np.array(n_agg)
             with torch.no_grad():
-                out["eval_logits"] = net(x).numpy()[:, :, 0]
+                out["eval_logits"] = net(x).numpy()[:, :, 0] if task == "class" else net(x).numpy()
         del net, logits, loss, grads
     return out
 
@@ -209,6 +211,7 @@ def main():
         "train_M_2x4x111_s1": lambda: train_case(ref, "M", 2, 4, 111, 1),
         "train_M_2x4x158_s2": lambda: train_case(ref, "M", 2, 4, 158, 2),
         "train_M_2x8x112_s1": lambda: train_case(ref, "M", 2, 8, 112, 1),
+        "trainloc_M_2x4x64_s1": lambda: train_case(ref, "M", 2, 4, 64, 1, task="loc"),
     }
     if args.big:
         jobs["train_M_8x16x224_s1"] = lambda: train_case(ref, "M", 8, 16, 224, 1)

@@ -73,6 +73,33 @@ def test_train_step_vs_reference_golden(golden_dir, case):
     assert parity.rel(ev.cpu().numpy()[:, :, 0], g["eval_logits"]) < parity.RTOL
 
 
+def test_loc_head_vs_reference_golden(golden_dir):
+    """task='loc' (x3d.py:240-241,340-343): per-frame logits [B, C, T], pooling over (H, W) only; forward, backward
+    (same label on every frame) and eval against the reference's golden."""
+    import x3d
+    dev = _dev()
+    g = _golden(golden_dir, "trainloc_M_2x4x64_s1")
+    B, T, H, S = [int(v) for v in g["shape"]]
+    net = x3d.generate_model("M", n_classes=400, dropout=0.0, base_bn_splits=S, task="loc")
+    net.load_state_dict(synthetic.procedural_state_dict(xo.state_template("M", 400, S), int(g["seed"][0])))
+    net.to(dev).train(True)
+    x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1])).to(dev)
+    y = synthetic.synthetic_labels(B, seed=int(g["seed"][1])).to(dev)
+    logits = net(x)
+    assert logits.shape == (B, 400, T)
+    loss = torch.nn.CrossEntropyLoss()(logits, y.expand(B, T))
+    loss.backward()
+    torch.cuda.synchronize()
+    parity.check_forward(logits.detach().cpu().numpy(), loss.item(), g)
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
+    parity.check_grads(grads, g, synthetic.gradient_sketch)
+    net.train(False)
+    net.aggregate_sub_bn_stats()
+    with torch.no_grad():
+        ev = net(x)
+    assert parity.rel(ev.cpu().numpy(), g["eval_logits"]) < parity.RTOL
+
+
 def test_eval_forward_config1_S(golden_dir):
     """BASELINE config 1: X3D-S eval forward on (2,3,13,160,160)."""
     dev = _dev()

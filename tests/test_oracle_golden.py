@@ -65,6 +65,32 @@ def test_train_step_matches_reference(golden_dir, case):
     assert _rel(ev[:, :, 0].numpy(), g["eval_logits"]) < RTOL
 
 
+def test_loc_head_matches_reference(golden_dir):
+    """oracle forward(task='loc') + per-frame CE against the reference's task='loc' golden.  Run in fp64 against the
+    reference's fp64 entries (1e-9): at B=2, T=4, 64^2 the fp32 rounding noise of the gradient is ten times the
+    single draw stored as the floor, so the fp32-vs-fp32 comparison says little here; fp32 forward is still checked."""
+    g = _load(golden_dir, "trainloc_M_2x4x64_s1")
+    B, T, H, S = [int(v) for v in g["shape"]]
+    torch.set_num_threads(8)
+    sd = synthetic.procedural_state_dict(xo.state_template("M", 400, S), int(g["seed"][0]))
+    x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1]))
+    y = synthetic.synthetic_labels(B, seed=int(g["seed"][1]))
+    logits32 = xo.forward(x, sd, "M", S, True, {}, task="loc")
+    assert tuple(logits32.shape) == (B, 400, T)
+    parity.check_forward(logits32.numpy(), torch.nn.functional.cross_entropy(logits32, y.expand(B, T)).item(), g, rtol=RTOL)
+    leaf = {k: (v.double().detach().clone().requires_grad_(True) if xo.is_parameter(k)
+                else (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    logits = xo.forward(x.double(), leaf, "M", S, True, {}, task="loc")
+    loss = torch.nn.functional.cross_entropy(logits, y.expand(B, T))
+    names = [k for k in leaf if xo.is_parameter(k)]
+    gs = torch.autograd.grad(loss, [leaf[k] for k in names])
+    assert names == list(g["grad_names"])
+    assert _rel(logits.detach().numpy(), g["logits64"]) < 1e-9
+    assert abs(loss.item() - float(g["loss64"])) < 1e-9 * abs(float(g["loss64"]))
+    norms = np.array([float(v.norm()) for v in gs])
+    assert np.max(np.abs(norms - g["grad_norms64"]) / (g["grad_norms64"] + 1e-9 * float(g["grad_global_norm64"]))) < 1e-7
+
+
 def test_eval_forward_S_config1(golden_dir):
     g = _load(golden_dir, "eval_S_2x13x160")
     sd = synthetic.procedural_state_dict(xo.state_template("S", 400, 1), 0)

@@ -464,31 +464,36 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __res
     }
 }
 
+// segs = 1: AdaptiveAvgPool3d((1,1,1)) (task 'class', x3d.py:239); segs = T: AdaptiveAvgPool3d((None,1,1)) (task 'loc',
+// x3d.py:241): segment s of a (n, c) row is the contiguous plane s (P / segs elements).  pooled is [N][C][segs].
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ a5, const float* __restrict__ c5,
-                                                               float* __restrict__ pooled, int P) {
+                                                               float* __restrict__ pooled, int P, int segs) {
     __shared__ float red[4];
-    const int row = blockIdx.x;
+    const int row = blockIdx.x / segs, seg = blockIdx.x - row * segs;
+    const int Ps = P / segs;
     const float sc = c5[(size_t)row * 2], sh = c5[(size_t)row * 2 + 1];
-    const float* p = a5 + (size_t)row * P;
+    const float* p = a5 + (size_t)row * P + (size_t)seg * Ps;
     float v[1] = {0.f};
-    for (int i = threadIdx.x; i < P; i += 256) v[0] += fmaxf(fmaf(sc, p[i], sh), 0.f);
+    for (int i = threadIdx.x; i < Ps; i += 256) v[0] += fmaxf(fmaf(sc, p[i], sh), 0.f);
     float o[1];
     block_sum_256<1>(v, red, o);
-    if (threadIdx.x == 0) pooled[row] = o[0] / (float)P;
+    if (threadIdx.x == 0) pooled[blockIdx.x] = o[0] / (float)Ps;
 }
 
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __restrict__ a5, const float* __restrict__ c5,
                                                                const float* __restrict__ dpooled, float* __restrict__ g,
-                                                               float* __restrict__ partial, int P, int tiles) {
+                                                               float* __restrict__ partial, int P, int tiles, int segs) {
     __shared__ float red[4 * 2];
     const int row = blockIdx.y;
+    const int Ps = P / segs;
     const float sc = c5[(size_t)row * 2], sh = c5[(size_t)row * 2 + 1];
-    const float d = dpooled[row] / (float)P;
+    const float inv = 1.f / (float)Ps;
     const size_t base = (size_t)row * P;
     const int p0 = blockIdx.x * EW_TILE;
     float v[2] = {0.f, 0.f};
     for (int p = p0 + threadIdx.x; p < min(P, p0 + EW_TILE); p += 256) {
         const float a = a5[base + p];
+        const float d = dpooled[(size_t)row * segs + (segs == 1 ? 0 : p / Ps)] * inv;
         const float gg = fmaf(sc, a, sh) > 0.f ? d : 0.f;
         g[base + p] = gg;
         v[0] += gg;
@@ -639,20 +644,22 @@ extern "C" int x3d_bn_add_relu_bwd(const float* dout, const float* out, const fl
     return X3D_OK;
 }
 
-extern "C" int x3d_bn_relu_pool_fwd(const float* a5, const float* c5, float* pooled, int N, int C, int P,
+extern "C" int x3d_bn_relu_pool_fwd(const float* a5, const float* c5, float* pooled, int N, int C, int P, int segs,
                                     void* stream) {
-    X3D_CHECK_ARG(a5 && c5 && pooled && N > 0 && C > 0 && P > 0);
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, a5, c5, pooled, P);
+    X3D_CHECK_ARG(a5 && c5 && pooled && N > 0 && C > 0 && P > 0 && segs > 0 && P % segs == 0);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(N * C * segs), dim3(256), 0, (hipStream_t)stream, a5, c5, pooled, P,
+                       segs);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
 
 extern "C" int x3d_bn_relu_pool_bwd(const float* a5, const float* c5, const float* dpooled, float* g, float* partial,
-                                    int N, int C, int P, void* stream) {
+                                    int N, int C, int P, int segs, void* stream) {
     X3D_CHECK_ARG(a5 && c5 && dpooled && g && partial && N > 0 && C > 0 && P > 0 && N * C <= 65535);
+    X3D_CHECK_ARG(segs > 0 && P % segs == 0);
     const int tiles = cdiv(P, EW_TILE);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel, dim3(tiles, N * C), dim3(256), 0, (hipStream_t)stream, a5, c5, dpooled,
-                       g, partial, P, tiles);
+                       g, partial, P, tiles, segs);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

@@ -284,8 +284,6 @@ class ResNet(nn.Module):
                                       "hand-written MI355X kernels and has no CPU path")
         _hiplib.lib()   # raises when libx3dhip.so is missing
         x = x.contiguous().float()
-        if self.task == 'loc':
-            raise NotImplementedError("task='loc' head (x3d.py:240-241,340-343) is not built yet")
         if self.training and torch.is_grad_enabled():
             pooled = _engine.TrunkFunction.apply(self, x, *_engine.trunk_parameters(self))
             self._pending_tracked += 1
@@ -294,8 +292,14 @@ class ResNet(nn.Module):
                 pooled = _engine.trunk_forward(self, x, self.training, None)
             if self.training:
                 self._pending_tracked += 1
-        # head (x3d.py:333-339): 1x1x1 conv on the pooled vector == linear; tiny GEMMs
-        h = F.relu(F.linear(pooled, self.fc1.weight.view(self.fc1.weight.shape[0], -1)))
+        # head (x3d.py:333-343): 1x1x1 conv on the pooled vector(s) == linear; tiny GEMMs
+        w1 = self.fc1.weight.view(self.fc1.weight.shape[0], -1)
+        if self.task == 'loc':
+            # pooled [B, C5, T]: per-frame features -> [B, T, 2048] -> dropout -> fc2 -> [B, n_classes, T]
+            h = F.relu(F.linear(pooled.permute(0, 2, 1), w1))
+            h = self.dropout(h)
+            return self.fc2(h).permute(0, 2, 1)
+        h = F.relu(F.linear(pooled, w1))
         h = self.dropout(h)
         return self.fc2(h).unsqueeze(2)
 

@@ -131,8 +131,8 @@ def _bn_eval(bn, N):
 
 
 def trunk_forward(model, x, training, ctx=None):
-    """x: float32 [N,3,T,H,W] on the GPU.  Returns pooled features [N, C5] (the input of
-    the head's fc1, x3d.py:331-333).  ctx (TrunkContext) collects what backward needs."""
+    """x: float32 [N,3,T,H,W] on the GPU.  Returns pooled features [N, C5] (task 'class') or [N, C5, T] (task 'loc',
+    x3d.py:241) -- the input of the head's fc1 (x3d.py:331-333).  ctx (TrunkContext) collects what backward needs."""
     N, _, T, H, W = x.shape
     S = model.bn1.num_splits
     packs = weight_packs(model)
@@ -164,7 +164,7 @@ def trunk_forward(model, x, training, ctx=None):
         c5, save5, _ = _bn_train(p5, model.bn5, S, P5)
     else:
         c5, save5 = _bn_eval(model.bn5, N), None
-    pooled = ops.bn_relu_pool_fwd(a5, c5)
+    pooled = ops.bn_relu_pool_fwd(a5, c5, per_frame=getattr(model, "task", "class") == "loc")
     if ctx is not None:
         ctx.head = dict(x4=cur_raw, a5=a5, c5=c5, save5=save5, S=S, w5t=packs.get(model.conv5.weight, True))
     return pooled

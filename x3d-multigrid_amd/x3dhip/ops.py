@@ -284,13 +284,15 @@ def bn_add_relu_bwd(dout, out, a3, ad=None, g=None):
     return g, partial, partial_d
 
 
-def bn_relu_pool_fwd(a5, c5):
+def bn_relu_pool_fwd(a5, c5, per_frame=False):
+    """per_frame=False: pooled [N, C] (task 'class'); True: [N, C, T] (task 'loc', pooling over H, W only)."""
     _need_cuda(a5, c5)
     L = _lib.lib()
     N, C = a5.shape[:2]
     P = a5[0, 0].numel()
-    pooled = _f((N, C), a5)
-    check(L.x3d_bn_relu_pool_fwd(ptr(a5), ptr(c5), ptr(pooled), N, C, P, _lib.stream()))
+    segs = a5.shape[2] if per_frame else 1
+    pooled = _f((N, C, segs) if per_frame else (N, C), a5)
+    check(L.x3d_bn_relu_pool_fwd(ptr(a5), ptr(c5), ptr(pooled), N, C, P, segs, _lib.stream()))
     return pooled
 
 
@@ -301,7 +303,8 @@ def bn_relu_pool_bwd(a5, c5, dpooled, g=None):
     P = a5[0, 0].numel()
     g = g if g is not None else _f(a5.shape, a5)
     partial = _f((N, C, L.x3d_ew_tiles(P), 2), a5)
-    check(L.x3d_bn_relu_pool_bwd(ptr(a5), ptr(c5), ptr(dpooled), ptr(g), ptr(partial), N, C, P, _lib.stream()))
+    segs = dpooled.shape[2] if dpooled.dim() == 3 else 1
+    check(L.x3d_bn_relu_pool_bwd(ptr(a5), ptr(c5), ptr(dpooled), ptr(g), ptr(partial), N, C, P, segs, _lib.stream()))
     return g, partial
 
 
