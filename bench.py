@@ -242,6 +242,11 @@ def main():
         "config": {"workload": "X3D-M train step B=%d/GPU T=%d H=W=%d, 400 classes, dropout 0.5, SGD momentum" % (B, T, H),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "launch": "eager" if args.no_graph else "hipGraph(fwd+bwd) + SGD",
+                   # storage, forward GEMMs, stencils, BN: fp32.  Backward pointwise GEMMs: fp32 operands split into
+                   # hi+lo bf16 (3 MFMA products, fp32 accumulate, ~2^-16 per product; parity-verified)
+                   # unless X3D_DGRAD_F32 / X3D_WGRAD_F32 select the exact fp32-MFMA kernels
+                   "backward_gemm": ("fp32 MFMA" if os.environ.get("X3D_DGRAD_F32") else "split-bf16x3 dgrad") + " / " +
+                                    ("fp32 MFMA" if os.environ.get("X3D_WGRAD_F32") else "split-bf16x3 wgrad"),
                    "loss": round(float(loss), 4)},
         "step_hbm_roofline": {"algorithmic_bytes_per_step": step_bytes,
                               "achieved_GBs": round(step_bytes / (ms * 1e-3) / 1e9, 1),

@@ -11,7 +11,7 @@ import glob
 import json
 import sys
 
-FAMILY = [("pw_wgrad", "pw_bwd_weight"), ("pw4_kernel", "pw"), ("pw2_kernel", "pw"), ("pw3_kernel", "pw"), ("pw_kernel", "pw"),
+FAMILY = [("pw_wgrad", "pw_bwd_weight"), ("pw5_kernel", "pw"), ("pw4_kernel", "pw"), ("pw2_kernel", "pw"), ("pw3_kernel", "pw"), ("pw_kernel", "pw"),
           ("dw_fwd_kernel", "dw333_fwd"), ("dw_bwd_kernel", "dw333_bwd"), ("bn_add_relu_fwd", "bn_add_relu_fwd"),
           ("bn_add_relu_bwd", "bn_add_relu_bwd"), ("dw5t_fwd", "dw5t_fwd"), ("dw5t_bwd", "dw5t_bwd"),
           ("stem133_fwd", "stem133_fwd"), ("stem133_wgrad", "stem133_bwd_weight")]
