@@ -41,6 +41,7 @@ cases = {
     "pw_l3": (8, 216, 96, 16, 14, 14),
     "pw_l3b": (8, 96, 216, 16, 14, 14),
     "pw_l2": (8, 108, 48, 16, 28, 28),
+    "pw_l2b": (8, 48, 108, 16, 28, 28),
     "pw_l1": (8, 24, 54, 16, 56, 56),
     "pw_l1b": (8, 54, 24, 16, 56, 56),
     "pw_l10": (8, 24, 54, 16, 112, 112),
