@@ -121,3 +121,35 @@ def test_validate_matches_oracle_multi_crop():
         corr += int((sm.max(1)[1] == y.view(b, 1)).sum())
     assert abs(loss - tot / 2) / (tot / 2) < 1e-3
     assert acc == corr / (2 * b)
+
+
+def test_split_graph_backward_equals_single_graph(monkeypatch):
+    """The two-graph backward used for data-parallel overlap (graph A: forward + head + layer4/3 backward, graph B:
+    layer2/1 + stem backward, all-reduce bucket in between) gives the same loss and bit-identical gradients as the
+    single captured graph."""
+    import x3d as resnet_x3d
+    from oracle import x3d_oracle as xo
+    from x3dhip import synthetic
+    from x3dhip.trainer import Trainer
+    dev = torch.device("cuda:0")
+    x = synthetic.synthetic_clips(4, 4, 64, 64, seed=5).to(dev)
+    y = synthetic.synthetic_labels(4, seed=5).to(dev)
+    res = []
+    for split in (False, True):
+        if split:
+            monkeypatch.setenv("X3D_FORCE_SPLIT", "1")
+        else:
+            monkeypatch.delenv("X3D_FORCE_SPLIT", raising=False)
+        model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=2)
+        model.load_state_dict(synthetic.procedural_state_dict(xo.state_template("M", 400, 2), 1))
+        model.to(dev).train(True)
+        tr = Trainer(model, lr=0.05, use_graph=True)
+        assert tr._overlap() == split
+        for _ in range(2):                       # capture + one replay
+            loss, logits = tr.train_step(x, y)
+        torch.cuda.synchronize()
+        res.append((float(loss), tr.fp.grad.clone(), tr.fp.flat.clone(), int(model.state_dict()["bn1.split_bn.num_batches_tracked"])))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2])
+    assert res[0][3] == res[1][3] == 2

@@ -247,24 +247,40 @@ class _GradSink:
         self.written[p] = t
 
 
-def trunk_backward(model, ctx, dpooled, grads):
-    """dpooled: [N, C5] gradient w.r.t. trunk_forward's result.  Fills grads.written[param] for
-    every trunk parameter (grads: _GradSink)."""
-    hd = ctx.head
-    S = hd["S"]
-    a5 = hd["a5"]
-    P5 = a5[0, 0].numel()
-    g5, pp = ops.bn_relu_pool_bwd(a5, hd["c5"], dpooled.contiguous())
-    _bn_bwd(grads, pp, S, P5, model.bn5, hd["save5"], out_cb=True)
-    cb5 = grads.last_cb
-    _wgrad(grads, model.conv5.weight, g5, a5, cb5, hd["x4"])
-    dcur, _ = ops.pw_bwd_data(g5, a5, cb5, _w2d(model.conv5.weight), wpt=hd["w5t"])
-    del g5
+def trunk_backward(model, ctx, dpooled, grads, part="all", state=None):
+    """dpooled: gradient w.r.t. trunk_forward's result ([N, C5], or [N, C5, T] for task 'loc').  Fills
+    grads.written[param] for every trunk parameter (grads: _GradSink).
 
-    pstem = None
-    for rec in reversed(ctx.blocks):
-        dcur, pstem = _block_backward(rec, dcur, grads)
+    part = "all": the whole backward.  "late": head, layer4, layer3 only -- returns the state for
+    part = "early" (layer2, layer1, stem), so that the gradient exchange of the late parameters (x3dhip/trainer.py,
+    first bucket) can run while the early layers' backward executes.  Every part ends with the side stream
+    joined: when it returns, all gradients of its parameters are ordered before later work on the current stream."""
+    n_late = len(model.layer3) + len(model.layer4)
+    blocks = list(reversed(ctx.blocks))
+    if part in ("all", "late"):
+        hd = ctx.head
+        S = hd["S"]
+        a5 = hd["a5"]
+        P5 = a5[0, 0].numel()
+        g5, pp = ops.bn_relu_pool_bwd(a5, hd["c5"], dpooled.contiguous())
+        _bn_bwd(grads, pp, S, P5, model.bn5, hd["save5"], out_cb=True)
+        cb5 = grads.last_cb
+        _wgrad(grads, model.conv5.weight, g5, a5, cb5, hd["x4"])
+        dcur, _ = ops.pw_bwd_data(g5, a5, cb5, _w2d(model.conv5.weight), wpt=hd["w5t"])
+        del g5
+        pstem = None
+        for rec in (blocks if part == "all" else blocks[:n_late]):
+            dcur, pstem = _block_backward(rec, dcur, grads)
+        if part == "late":
+            if grads.side is not None:
+                torch.cuda.current_stream().wait_stream(grads.side)
+            return dcur, pstem
+    else:
+        dcur, pstem = state
+        for rec in blocks[n_late:]:
+            dcur, pstem = _block_backward(rec, dcur, grads)
 
+    S = ctx.head["S"]
     st = ctx.stem
     a_t = st["a_t"]
     P = a_t[0, 0].numel()
@@ -276,6 +292,7 @@ def trunk_backward(model, ctx, dpooled, grads):
     grads.put(w_s, ops.stem133_bwd_weight(st["x"], dx_s, w_s.shape, out=grads.out(w_s)))
     if grads.side is not None:
         torch.cuda.current_stream().wait_stream(grads.side)
+    return None
 
 
 def _bn_bwd(grads, partial, S, count, bn, save, out_cb=True):

@@ -7,6 +7,8 @@ same shape on its share of the batch, gradients are summed with one bucketed all
 the flat buffer (15.18 MB fp32 for X3D-M) and divided by the world size inside the fused SGD
 kernel; BN statistics stay local to the rank (DataParallel semantics).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -76,6 +78,25 @@ class GradReducer:
                 dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.pg)
         cur.wait_stream(self.stream)
 
+    def start_bucket(self, i):
+        """Enqueue the all-reduce of bucket i behind everything on the current stream WITHOUT making the current
+        stream wait for it: the caller keeps launching backward kernels (x3dhip.trainer: the early layers) while
+        the bucket travels over xGMI.  finish() joins."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        a, b = self.buckets[i]
+        if self.stream is None:
+            dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+
+    def finish(self):
+        if self.world > 1 and self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
 
 class Trainer:
     """Optimizer-like object (``param_groups``, ``state_dict`` in torch.optim.SGD's format) that
@@ -128,11 +149,14 @@ class Trainer:
     def train_step(self, x, y, pre_step=None):
         """forward + CE + backward (+ all-reduce) + SGD.  ``pre_step`` runs after backward and
         before the parameter update (where the reference calls lr_warmup, train...:274)."""
-        if self.use_graph:
-            loss, logits = self._graphed_fwd_bwd(x, y)
+        if self.use_graph and self._overlap():
+            loss, logits = self._graphed_split(x, y)        # all-reduce issued inside, overlapped with the early layers
         else:
-            loss, logits = self._fwd_bwd(x, y)
-        self._allreduce()
+            if self.use_graph:
+                loss, logits = self._graphed_fwd_bwd(x, y)
+            else:
+                loss, logits = self._fwd_bwd(x, y)
+            self._allreduce()
         if pre_step is not None:
             pre_step()
         self._sgd()                          # outside any graph: lr / first-step flag are host values
@@ -148,6 +172,73 @@ class Trainer:
         ent["y"].copy_(y)
         ent["fb"].replay()
         self.model._pending_tracked += 1     # the replayed forward advanced every split-BN once
+        return ent["loss"], ent["logits"]
+
+    # -- data parallel: backward captured as two graphs around the first gradient bucket ---------
+    def _overlap(self):
+        """Split capture is used for multi-rank runs (X3D_NO_OVERLAP=1 disables it; X3D_FORCE_SPLIT=1 enables it on a
+        single rank for tests), task 'class', with the two-bucket layout."""
+        if os.environ.get("X3D_NO_OVERLAP") == "1" or len(self.reducer.buckets) != 2:
+            return False
+        if getattr(self.model, "task", "class") != "class" or not self.model.training:
+            return False
+        return self.world > 1 or os.environ.get("X3D_FORCE_SPLIT") == "1"
+
+    def _fwd_bwd_late(self, x, y):
+        """Graph A: zero grads, forward, loss, head backward, trunk backward of conv5 / layer4 / layer3."""
+        from . import engine
+        model = self.model
+        self.fp.grad.zero_()
+        tctx = engine.TrunkContext()
+        with torch.no_grad():
+            pooled = engine.trunk_forward(model, x.contiguous().float(), True, tctx)
+        pooled = pooled.detach().requires_grad_(True)
+        h = F.relu(F.linear(pooled, model.fc1.weight.view(model.fc1.weight.shape[0], -1)))       # x3d.py:333-339
+        logits = model.fc2(model.dropout(h)).unsqueeze(2)
+        loss = F.cross_entropy(logits, y)
+        loss.backward(inputs=[pooled, model.fc1.weight, model.fc2.weight, model.fc2.bias])       # into the flat .grad views
+        side = None if os.environ.get("X3D_NO_SIDE_STREAM") == "1" else engine.side_stream(x.device)
+        sink = engine._GradSink(True, side)
+        state = engine.trunk_backward(model, tctx, pooled.grad, sink, part="late")
+        return loss.detach(), logits.detach(), tctx, sink, state
+
+    def _capture_split(self, x, y):
+        from . import engine
+        sx, sy = x.clone(), y.clone()
+        bn_state = {k: v.clone() for k, v in self.model.state_dict().items() if "running_" in k}
+        pending = self.model._pending_tracked
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):                                  # allocator / lazy-init warm-up, eager
+                _, _, tctx, sink, state = self._fwd_bwd_late(sx, sy)
+                engine.trunk_backward(self.model, tctx, None, sink, part="early", state=state)
+        torch.cuda.current_stream().wait_stream(s)
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            loss, logits, tctx, sink, state = self._fwd_bwd_late(sx, sy)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            engine.trunk_backward(self.model, tctx, None, sink, part="early", state=state)
+        self.model._pending_tracked = pending
+        sd = self.model.state_dict()
+        for k, v in bn_state.items():
+            sd[k].copy_(v)
+        return dict(x=sx, y=sy, ga=ga, gb=gb, loss=loss, logits=logits, keep=(tctx, sink, state))
+
+    def _graphed_split(self, x, y):
+        key = ("split", tuple(x.shape), self.model._bn_version)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._capture_split(x, y)
+            self._graphs[key] = ent
+        ent["x"].copy_(x)
+        ent["y"].copy_(y)
+        ent["ga"].replay()
+        self.reducer.start_bucket(0)          # head + layer4 + layer3 gradients: on the wire while graph B runs
+        ent["gb"].replay()
+        self.reducer.start_bucket(1)
+        self.reducer.finish()
+        self.model._pending_tracked += 1
         return ent["loss"], ent["logits"]
 
     def invalidate_graphs(self):
