@@ -97,21 +97,28 @@ __global__ void bn_eval_coef_kernel(const float* __restrict__ rmean, const float
 constexpr int BN_MAXS = 256;
 constexpr int BN_MAXN = 1024;
 
-// Per-sample row sums for one channel: wave w takes samples w, w+4, ...; lanes stride the tiles;
-// fp64 wave reduction by shuffles (no barrier per sample, loads of consecutive samples overlap).
+// Per-sample row sums for one channel.  A group of G lanes (G = tiles rounded up to a power of two, <= 64) owns one
+// sample, so a wave reduces 64 / G samples per pass (the depthwise partials have 1-4 tiles per sample, the large-batch
+// multigrid shapes up to 128 samples); lanes stride the tiles; fp64 butterfly inside the group.  Lanes beyond `tiles`
+// contribute exact zeros, so the result does not depend on G.
 __device__ __forceinline__ void channel_row_sums(const float* __restrict__ partial, int N, int C, int c, int tiles,
                                                  double* rows /* [N][2] in LDS */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int n = wave; n < N; n += 4) {
-        const float* p = partial + ((size_t)n * C + c) * tiles * 2;
+    int G = 1;
+    while (G < tiles && G < 64) G <<= 1;
+    const int spw = 64 / G, sub = lane / G, l = lane - sub * G;
+    for (int n0 = wave * spw; n0 < N; n0 += 4 * spw) {
+        const int n = n0 + sub;
+        const bool ok = n < N;
+        const float* p = partial + ((size_t)(ok ? n : 0) * C + c) * tiles * 2;      // clamped: no load under a lane branch
         double a = 0.0, b = 0.0;
-        for (int t = lane; t < tiles; t += 64) {
+        for (int t = l; t < tiles; t += G) {
             const float2 v = *reinterpret_cast<const float2*>(p + 2 * t);
             a += (double)v.x;
             b += (double)v.y;
         }
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-        if (lane == 0) { rows[2 * n] = a; rows[2 * n + 1] = b; }
+        for (int o = G >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (l == 0 && ok) { rows[2 * n] = a; rows[2 * n + 1] = b; }
     }
     __syncthreads();
 }
@@ -249,6 +256,7 @@ __device__ __forceinline__ void bn_bwd_finalize_channel(int c, const double* __r
     for (int j = 0; j < S; ++j) {
         const double mean = save[(size_t)j * C + c], invstd = save[(size_t)(S + j) * C + c];
         double sg = 0.0, sgx = 0.0;
+#pragma unroll 4
         for (int n = j; n < N; n += S) {
             const double d0 = dsum[((size_t)n * C + c) * 2], d1 = dsum[((size_t)n * C + c) * 2 + 1];
             if (se != nullptr) {
@@ -342,17 +350,67 @@ __device__ __forceinline__ void se_wgrad_element(int i, int N, int C, int Wd, co
                                 float* __restrict__ db2) {
     const int c = i / Wd, w = i - c * Wd;
     double a2 = 0.0, a1 = 0.0, bb2 = 0.0, bb1 = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const double d2 = dz2[(size_t)n * C + c], d1 = dz1[(size_t)n * Wd + w];
-        a2 += d2 * (double)save_z[(size_t)n * Wd + w];
-        a1 += d1 * (double)save_pool[(size_t)n * C + c];
-        bb2 += d2;
-        bb1 += d1;
+    // samples in batches of eight: the 32 independent loads of a batch are issued together (clamped sample index), then
+    // accumulated in sample order -- at N = 128 (multigrid long cycle 0) a one-sample-at-a-time loop is 128 serial round trips
+    for (int n0 = 0; n0 < N; n0 += 8) {
+        float v2[8], v1[8], vz[8], vp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = min(n0 + u, N - 1);
+            v2[u] = dz2[(size_t)n * C + c];
+            v1[u] = dz1[(size_t)n * Wd + w];
+            vz[u] = save_z[(size_t)n * Wd + w];
+            vp[u] = save_pool[(size_t)n * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (n0 + u < N) {
+                const double d2 = v2[u], d1 = v1[u];
+                a2 += d2 * (double)vz[u];
+                a1 += d1 * (double)vp[u];
+                bb2 += d2;
+                bb1 += d1;
+            }
+        }
     }
     dw2[(size_t)c * Wd + w] = (float)a2;
     dw1[(size_t)w * C + c] = (float)a1;
     if (w == 0) db2[c] = (float)bb2;
     if (c == 0) db1[w] = (float)bb1;
+}
+
+// Wave-per-channel form of bn_bwd_finalize_channel for the SE-scaled BN (64 % S == 0): lane l owns samples l, l + 64, ...
+// (all of split l % S); fp64 butterflies over the lanes of one residue give the split sums, over the residues the
+// channel sums.  At N = 128 the thread-per-channel loop is 128 serial round trips of five loads in one or two workgroups.
+__device__ __forceinline__ void bn_bwd_finalize_wave(int c, int lane, const double* __restrict__ dsum, int N, int C, int S,
+                                                     int count, const float* __restrict__ gamma, const float* __restrict__ save,
+                                                     const float* __restrict__ se, const float* __restrict__ dpool,
+                                                     const float* __restrict__ nsum, float* __restrict__ cb,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int j = lane % S;
+    const double M = (double)count * (double)(N / S);
+    const double g = gamma[c];
+    const double mean = save[(size_t)j * C + c], invstd = save[(size_t)(S + j) * C + c];
+    double sg = 0.0, sgx = 0.0;
+    for (int n = lane; n < N; n += 64) {
+        const double d0 = dsum[((size_t)n * C + c) * 2], d1 = dsum[((size_t)n * C + c) * 2 + 1];
+        const double sv = se[(size_t)n * C + c], dp = dpool[(size_t)n * C + c];
+        sg += sv * d0 + dp;
+        sgx += sv * (d1 - mean * d0) * invstd +
+               (dp / (double)count) * ((double)nsum[(size_t)n * C + c] - (double)count * mean) * invstd;
+    }
+    for (int o = 32; o >= S; o >>= 1) { sg += __shfl_xor(sg, o); sgx += __shfl_xor(sgx, o); }     // split totals
+    double dg = sgx, db = sg;
+    for (int o = S >> 1; o > 0; o >>= 1) { dg += __shfl_xor(dg, o); db += __shfl_xor(db, o); }       // channel totals
+    const double k = g * invstd;
+    const double Bc = -k * invstd * sgx / M;
+    const double Cbase = -k * sg / M + k * invstd * mean * sgx / M;
+    for (int n = lane; n < N; n += 64) {
+        cb[((size_t)n * C + c) * 3] = (float)(k * (double)se[(size_t)n * C + c]);
+        cb[((size_t)n * C + c) * 3 + 1] = (float)Bc;
+        cb[((size_t)n * C + c) * 3 + 2] = (float)(Cbase + k * (double)dpool[(size_t)n * C + c] / (double)count);
+    }
+    if (lane == 0) { dgamma[c] = (float)dg; dbeta[c] = (float)db; }
 }
 
 // One launch for the two independent consumers of the per-sample SE backward: blocks [0, nbw) compute the SE weight
@@ -369,6 +427,9 @@ __global__ __launch_bounds__(256) void se_tail_kernel(int nbw, const double* __r
     if ((int)blockIdx.x < nbw) {
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < C * Wd) se_wgrad_element(i, N, C, Wd, dz2, dz1, save_z, save_pool, dw1, db1, dw2, db2);
+    } else if (64 % S == 0) {
+        const int c = ((int)blockIdx.x - nbw) * 4 + (threadIdx.x >> 6);                  // one wave per channel
+        if (c < C) bn_bwd_finalize_wave(c, threadIdx.x & 63, dsum, N, C, S, count, gamma, save, se, dpool, nsum, cb, dgamma, dbeta);
     } else {
         const int c = ((int)blockIdx.x - nbw) * 256 + threadIdx.x;
         if (c < C) bn_bwd_finalize_channel(c, dsum, N, C, S, count, gamma, save, se, dpool, nsum, cb, dgamma, dbeta, 0);
@@ -608,7 +669,7 @@ extern "C" int x3d_se_bn_bwd_finalize(const float* partial, int N, int C, int ti
     hipLaunchKernelGGL(se_bwd_sample_kernel, dim3(N), dim3(256), 0, s, dsum, C, S, Wd, gamma, beta, save, w1, w2,
                        save_se, save_z, dpool, dz2, dz1);
     const int nbw = cdiv(C * Wd, 256);
-    hipLaunchKernelGGL(se_tail_kernel, dim3(nbw + cdiv(C, 256)), dim3(256), 0, s, nbw, dsum, N, C, S, count, Wd, gamma, save,
+    hipLaunchKernelGGL(se_tail_kernel, dim3(nbw + (64 % S == 0 ? cdiv(C, 4) : cdiv(C, 256))), dim3(256), 0, s, nbw, dsum, N, C, S, count, Wd, gamma, save,
                        save_se, dpool, nsum, cb, dgamma, dbeta, dz2, dz1, save_z, save_pool, dw1, db1, dw2, db2);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
