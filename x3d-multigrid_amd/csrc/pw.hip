@@ -913,22 +913,24 @@ __global__ __launch_bounds__(256, 2) void pw4_kernel(const PwArgs A) {
     const int K = A.K, P = A.P, M = A.M;
     const int kgroups = (K + 15) / 16, nchunks = (K + P4_KC - 1) / P4_KC;
     const int mt_run = A.mt_run, mblocks = A.mblocks;
-    const int per_n = ((A.tiles + 7) / 8) * 8 * mblocks;
-    const int items = per_n * A.N;
+    // item = ((voxel-tile group of 8) * mblocks + mb) * 8 + (voxel tile & 7), voxel tiles numbered over ALL samples
+    // (n * tiles + tile): item % 8 -- hence the XCD of the workgroup that owns it -- is the low tile bits, so the M
+    // blocks of one voxel tile share an XCD, and every workgroup has work even when a sample has < 8 tiles
+    const int VT = A.N * A.tiles;
+    const int items = ((VT + 7) / 8) * 8 * mblocks;
     const int mtl = (M + 15) / 16 - 1;              // last packed M tile
     const int G = gridDim.x;
 
-    auto decode = [&](int it, int& n, int& tile, int& mb) {
-        n = it / per_n;
-        const int rem = it - n * per_n;
-        const int tlo = rem & 7, rest = rem >> 3;
-        mb = rest % mblocks;
-        tile = (rest / mblocks) * 8 + tlo;
-    };
     auto next_valid = [&](int it, int& n, int& tile, int& mb) {
         while (it < items) {
-            decode(it, n, tile, mb);
-            if (tile < A.tiles) break;
+            const int tlo = it & 7, rest = it >> 3;
+            mb = rest % mblocks;
+            const int vt = (rest / mblocks) * 8 + tlo;
+            if (vt < VT) {
+                n = vt / A.tiles;
+                tile = vt - n * A.tiles;
+                break;
+            }
             it += G;
         }
         return it;
@@ -1193,25 +1195,27 @@ __global__ __launch_bounds__(256, 2) void pw5_kernel(const PwArgs A) {
     const int K = A.K, P = A.P, M = A.M;
     const int kg16 = (K + 15) / 16, kg32 = (K + 31) / 32, nchunks = kg32;
     const int mt_run = A.mt_run, mblocks = A.mblocks;
-    const int per_n = ((A.tiles + 7) / 8) * 8 * mblocks;
-    const int items = per_n * A.N;
+    // item = ((voxel-tile group of 8) * mblocks + mb) * 8 + (voxel tile & 7), voxel tiles numbered over ALL samples
+    // (n * tiles + tile): item % 8 -- hence the XCD of the workgroup that owns it -- is the low tile bits, so the M
+    // blocks of one voxel tile share an XCD, and every workgroup has work even when a sample has < 8 tiles
+    const int VT = A.N * A.tiles;
+    const int items = ((VT + 7) / 8) * 8 * mblocks;
     const int mtiles = (M + 15) / 16, mtl = mtiles - 1;
     const int G = gridDim.x;
     // split-bf16 planes sit behind the fp32 image of the transposed pack
     const __bf16* wqh = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
     const __bf16* wql = wqh + (size_t)mtiles * kg32 * 512;
 
-    auto decode = [&](int it, int& n, int& tile, int& mb) {
-        n = it / per_n;
-        const int rem = it - n * per_n;
-        const int tlo = rem & 7, rest = rem >> 3;
-        mb = rest % mblocks;
-        tile = (rest / mblocks) * 8 + tlo;
-    };
     auto next_valid = [&](int it, int& n, int& tile, int& mb) {
         while (it < items) {
-            decode(it, n, tile, mb);
-            if (tile < A.tiles) break;
+            const int tlo = it & 7, rest = it >> 3;
+            mb = rest % mblocks;
+            const int vt = (rest / mblocks) * 8 + tlo;
+            if (vt < VT) {
+                n = vt / A.tiles;
+                tile = vt - n * A.tiles;
+                break;
+            }
             it += G;
         }
         return it;
@@ -1460,7 +1464,7 @@ int launch_pw(PwArgs& A, hipStream_t s) {
     pw_plan(A.N, A.K, A.M, A.P, dense, &variant, &A.tiles, &A.mblocks, &A.mt_run);
     dim3 grid(cdiv(A.tiles, 8) * 8 * A.mblocks, A.N), block(256);
     if (variant == 3 && A.wp != nullptr) {
-        const int items = cdiv(A.tiles, 8) * 8 * A.mblocks * A.N;
+        const int items = cdiv(A.tiles * A.N, 8) * 8 * A.mblocks;
         dim3 pgrid(min(items, 512));            // two resident workgroups per CU walk the item list
         const int U = cdiv(A.mt_run, 2);
         if (IN == IN_BNBWD && EPI != EPI_STATS && getenv("X3D_DGRAD_F32") == nullptr) {
