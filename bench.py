@@ -253,14 +253,19 @@ def main():
                               "frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
-    if rank == 0 and not args.no_kernel_timing:
-        # one instrumented eager step: HIP events around every launch, same tensors
+    if not args.no_kernel_timing:
+        # one instrumented eager step: HIP events around every launch, same tensors.  EVERY rank runs these steps (they
+        # contain the gradient all-reduce: the collectives must match across ranks); only rank 0 records and reports.
         tr_e = tr
         tr_e.use_graph = False
         os.environ["X3D_NO_SIDE_STREAM"] = "1"      # serialise the weight-gradient kernels: clean per-kernel times
         for _ in range(2):          # eager warm-up: allocator + code objects outside the graph pool
             tr_e.step(x, y)
         torch.cuda.synchronize()
+        if rank != 0:
+            tr_e.step(x, y)
+            torch.cuda.synchronize()
+    if rank == 0 and not args.no_kernel_timing:
         with KernelTimer(ops) as kt:
             tr_e.step(x, y)
         agg = kt.summary()
@@ -286,8 +291,6 @@ def main():
                            "share_of_step_device_time": round(tms / tot, 3)}
         out["kernel_breakdown_ms"] = {k: [round(v[0], 3), v[2], round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0]
                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
-    elif world > 1 and not args.no_kernel_timing:
-        pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, H)
     if world > 1:

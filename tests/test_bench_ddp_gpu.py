@@ -20,7 +20,7 @@ def test_two_rank_bench_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--frames", "4", "--size", "64",
-           "--no-kernel-timing", "--no-cpu-baseline"]
+           "--no-cpu-baseline"]      # kernel timing stays ON: its eager steps contain collectives every rank must join
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
