@@ -127,3 +127,33 @@ def spatial(frame, x1, y1, crop_size, out_size, flip, mean=KINETICS_MEAN, std=KI
 def clip(frames, frame_idx, x1, y1, crop_size, out_size, flip, mean=KINETICS_MEAN, std=KINETICS_STD):
     """frames uint8 [Tsrc][H][W][3]; frame_idx = 0-based positions into frames -> float32 [3][T][S][S]."""
     return np.stack([spatial(frames[i], x1, y1, crop_size, out_size, flip, mean, std) for i in frame_idx], axis=1)
+
+
+def center_crop_box(width, height):
+    """CenterCropScaled.__call__ (spatial_transforms.py:214-228): the centred square of side min(w, h)."""
+    crop_size = min(width, height)
+    x1 = int(round((width - crop_size) / 2.))
+    y1 = int(round((height - crop_size) / 2.))
+    return x1, y1, crop_size
+
+
+def val_crop_indices(n_frames, gamma_tau, sample_duration, crops):
+    """kinetics.py:214-233 (the validation dataset): every gamma_tau-th frame of the video, `crops` temporal windows
+    of sample_duration // gamma_tau frames starting at 0, step, 2*step, ...  Returns `crops` lists of 0-based frames."""
+    strided = list(range(0, n_frames))[::gamma_tau]
+    frames = sample_duration // gamma_tau
+    step = int((len(strided) - 1 - frames) // (crops - 1))
+    if step == 0:
+        starts = [0] * crops
+    else:
+        starts = list(range(0, step * crops, step))
+    return [strided[s0:s0 + frames] for s0 in starts]
+
+
+def val_clips(frames, gamma_tau, sample_duration, crops, out_size, mean=KINETICS_MEAN, std=KINETICS_STD):
+    """frames uint8 [n][H][W][3] -> float32 [crops][3][T][S][S] (kinetics.py:205-239 with the validation transforms of
+    train_x3d_kinetics_multigrid.py:132-136)."""
+    n, h, w, _ = frames.shape
+    x1, y1, crop = center_crop_box(w, h)
+    return np.stack([clip(frames, idx, x1, y1, crop, out_size, False, mean, std)
+                     for idx in val_crop_indices(n, gamma_tau, sample_duration, crops)], axis=0)

@@ -43,7 +43,33 @@ def case(name, seed, n_frames, h, w, crop_size, c_size, num_frames, gamma_tau, s
     print(name, "idx", idx, "scale %.4f flip %s" % (crop_t.scale, flip_t.p < 0.5), clip.shape)
 
 
+def val_case(name, seed, n_frames, h, w, crop_size, gamma_tau, sample_duration, crops):
+    """Validation path: the reference's CenterCropScaled + ToTensor + Normalize classes on every gamma_tau-th frame,
+    then the multi-crop slicing of kinetics.py:219-233 (that file imports torchvision and cannot be imported here; its
+    five slicing lines are applied literally below)."""
+    fr = frames_u8(n_frames, h, w, seed)
+    spatial = st.Compose([st.CenterCropScaled(crop_size), st.ToTensor(255), st.Normalize(MEAN, STD)])      # train...:132-135
+    frame_indices = list(range(1, n_frames + 1))
+    frame_indices = frame_indices[::gamma_tau]                                                          # kinetics.py:219
+    frames = sample_duration // gamma_tau                                                               # :202
+    step = int((len(frame_indices) - 1 - frames) // (crops - 1))                                        # :220
+    spatial.randomize_parameters()
+    clip = [spatial(Image.fromarray(fr[i - 1])) for i in frame_indices]
+    clip = torch.stack(clip, 0).permute(1, 0, 2, 3)                                                     # :226
+    if step == 0:                                                                                       # :228-233
+        clips = [clip[:, :frames, ...] for i in range(crops)]
+    else:
+        clips = [clip[:, i:i + frames, ...] for i in range(0, step * crops, step)]
+    clips = torch.stack(clips, 0).numpy()
+    np.savez_compressed(os.path.join(HERE, "inputval_%s.npz" % name), frames_seed=seed, n_frames=n_frames, h=h, w=w,
+                        c_size=crop_size, gamma_tau=gamma_tau, sample_duration=sample_duration, crops=crops,
+                        step=step, clips=clips.astype(np.float32))
+    print("val", name, "step", step, clips.shape)
+
+
 if __name__ == "__main__":
+    val_case("a_60x80_to48", 21, 100, 60, 80, 48, 5, 40, 3)          # 20 strided frames, 8-frame crops, step 5
+    val_case("b_50x50_short", 22, 45, 50, 50, 32, 5, 40, 3)          # 9 strided frames: step 0 -> identical crops
     # (name, seed, source frames, H, W, crop_size of the schedule, c_size of this step, num_frames, gamma_tau, sample_duration)
     # sample_duration is the dataset's num_frames (= 16 * gamma_tau) divided by the long-cycle factor (kinetics_multigrid.py:205-209)
     case("a_96x128_to32", 1, 100, 96, 128, 224, 32, 16 * 5, 5, 80)       # 16 frames

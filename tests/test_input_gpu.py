@@ -110,3 +110,21 @@ def test_input_throughput_report(capsys):
     dt = (time.time() - t0) / n
     with capsys.disabled():
         print("\n[input pipeline] B=8 T=16 224^2 from 256x340 uint8: %.2f ms/batch = %.0f clips/s (host draws included)" % (dt * 1e3, 8 / dt))
+
+
+VGOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "inputval_*.npz")))
+
+
+@pytest.mark.parametrize("path", VGOLD, ids=[os.path.basename(p)[9:-4] for p in VGOLD])
+def test_validation_batch_matches_golden(path):
+    """DeviceVideoKinetics.val_batch: centre crop scaled + 3 temporal windows (kinetics.py:205-239) on the GPU"""
+    from kinetics_multigrid import DeviceVideoKinetics
+    dev = _dev()
+    g = np.load(path)
+    frames = synthetic_frames_u8(int(g["n_frames"]), int(g["h"]), int(g["w"]), int(g["frames_seed"]))
+    ds = DeviceVideoKinetics([torch.from_numpy(frames).to(dev)], [5], sample_duration=int(g["sample_duration"]),
+                             gamma_tau=int(g["gamma_tau"]), crop_size=int(g["c_size"]))
+    clips, y = ds.val_batch([0], crops=int(g["crops"]))
+    torch.cuda.synchronize()
+    assert tuple(clips.shape) == (1,) + g["clips"].shape and y.tolist() == [5]
+    assert np.array_equal(clips[0].cpu().numpy(), g["clips"])

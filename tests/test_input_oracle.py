@@ -38,3 +38,15 @@ def test_resize_restatement_is_pil_exact():
         a = rng.integers(0, 256, size=(crop, crop, 3), dtype=np.uint8)
         ref = np.asarray(Image.fromarray(a).resize((out, out), Image.BILINEAR))
         assert np.array_equal(io.resize_bilinear_u8(a, out), ref), (crop, out)
+
+
+VGOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "inputval_*.npz")))
+
+
+@pytest.mark.parametrize("path", VGOLD, ids=[os.path.basename(p)[9:-4] for p in VGOLD])
+def test_validation_clips_match_reference_transforms(path):
+    g = np.load(path)
+    frames = synthetic_frames_u8(int(g["n_frames"]), int(g["h"]), int(g["w"]), int(g["frames_seed"]))
+    clips = io.val_clips(frames, int(g["gamma_tau"]), int(g["sample_duration"]), int(g["crops"]), int(g["c_size"]))
+    assert clips.shape == g["clips"].shape
+    assert np.array_equal(clips, g["clips"])

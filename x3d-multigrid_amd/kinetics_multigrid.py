@@ -81,3 +81,21 @@ class DeviceVideoKinetics:
         clips = self.pre(samples, out=out)
         y = torch.tensor([[self.labels[i]] for i in indices], dtype=torch.int64, device=clips.device)
         return clips, y, long_cycle_state, stats
+
+    def val_batch(self, indices, crops=3, sample_duration=None, crop_size=None):
+        """The validation dataset's batch (kinetics.py:205-239 with the transforms of train...:132-136): for every video
+        `crops` temporal windows, centre crop scaled to crop_size, no flip.  Returns (clips float32
+        [B, crops, 3, T, S, S], labels int64 [B]) -- what train_x3d_kinetics_multigrid.validate consumes."""
+        from x3dhip.clip_input import center_crop_box, val_crop_indices
+        sd = self.sample_duration if sample_duration is None else sample_duration
+        S = self.crop_size if crop_size is None else crop_size
+        samples = []
+        for i in indices:
+            v = self.videos[i]
+            x1, y1, crop = center_crop_box(v.shape[2], v.shape[1])
+            for idx in val_crop_indices(v.shape[0], self.gamma_tau, sd, crops):
+                samples.append((v, dict(frame_idx=idx, x1=x1, y1=y1, crop=crop, out=S, flip=False)))
+        clips = self.pre(samples)
+        B = len(indices)
+        y = torch.tensor([self.labels[i] for i in indices], dtype=torch.int64, device=clips.device)
+        return clips.view(B, crops, *clips.shape[1:]), y

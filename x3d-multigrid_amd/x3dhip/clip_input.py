@@ -53,6 +53,26 @@ def draw_clip_params(n_frames, width, height, scales, c_size, num_frames, gamma_
                 scale=scale, tl_x=tl_x, tl_y=tl_y, p=p)
 
 
+def center_crop_box(width, height):
+    """CenterCropScaled (spatial_transforms.py:214-228): centred square of side min(w, h); Python's round (half to even)
+    like the reference."""
+    crop = min(width, height)
+    return int(round((width - crop) / 2.)), int(round((height - crop) / 2.)), crop
+
+
+def val_crop_indices(n_frames, gamma_tau, sample_duration, crops):
+    """Validation windows of kinetics.py:214-233: every gamma_tau-th frame, `crops` windows of sample_duration //
+    gamma_tau frames at 0, step, 2*step (step 0 -> identical windows).  0-based frame lists."""
+    strided = list(range(n_frames))[::gamma_tau]
+    frames = sample_duration // gamma_tau
+    step = int((len(strided) - 1 - frames) // (crops - 1))
+    if step < 0 or len(strided) < frames:
+        raise ValueError("video of %d frames is too short for %d-frame validation windows at stride %d" %
+                         (n_frames, frames, gamma_tau))
+    starts = [0] * crops if step == 0 else list(range(0, step * crops, step))
+    return [strided[s0:s0 + frames] for s0 in starts]
+
+
 _coeff_cache = {}
 
 
