@@ -23,9 +23,11 @@ def test_multigrid_loop_runs_through_all_long_cycles(tmp_path, capsys):
     import train_x3d_kinetics_multigrid as tr
     save = str(tmp_path / "ck_")
     steps, cps = tr.run(init_lr=0.01, warmup_steps=5, max_epochs=4, batch_size=2, steps=0, max_steps_run=38,
-                        iterations_per_epoch=10, save_model=save, save_every=20, use_graph=True, log_every=10)
+                        iterations_per_epoch=10, save_model=save, save_every=20, use_graph=True, log_every=10,
+                        val_every=15, val_batches=1, val_batch_size=1)
     out = capsys.readouterr().out
     assert steps == 38 and cps > 0
+    assert out.count(" val after step") == 2            # validation phase (aggregate BN, 3-crop eval) interleaved, training resumes
     # banners for long cycles 0,1,2,3 of phase 1 and the restart of phase 2 ...
     assert out.count("*****") >= 2 * 5
     assert "BN_splits 8 long_ind 0" in out and "BN_splits 1 long_ind 3" in out and "long_ind -1" in out

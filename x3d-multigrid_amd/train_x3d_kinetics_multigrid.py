@@ -143,7 +143,11 @@ def validate(model, batches):
 
 def run(init_lr=INIT_LR, warmup_steps=8000, max_epochs=120, batch_size=BS * BS_UPSCALE, steps=0, max_steps_run=None,
         iterations_per_epoch=None, load_ckpt=None, save_model='models/x3d_multigrid_kinetics_rgb_sgd_',
-        save_every=4000, use_graph=True, x3d_version=X3D_VERSION, log_every=20):
+        save_every=4000, use_graph=True, x3d_version=X3D_VERSION, log_every=20, val_every=None, val_batches=2,
+        val_batch_size=2, val_crops=3):
+    """The reference's training loop (train_x3d_kinetics_multigrid.py:157-292) on synthetic clips.  val_every: run the
+    validation phase (`validate`, the reference does it after every 4 training epochs, :195) every that many steps on
+    `val_batches` synthetic batches of [val_batch_size, val_crops, 3, T, H, W]."""
     from x3dhip.trainer import Trainer
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -230,6 +234,16 @@ def run(init_lr=INIT_LR, warmup_steps=8000, max_epochs=120, batch_size=BS * BS_U
                 dt = time.time() - t0
                 print(' step {} long {} shape ({},{},{}) loss {:.4f} acc {:.3f} lr {:.5f}  {:.1f} clips/s'.format(
                     steps, long_ind, B, T, H, tot_loss, acc, optimizer.param_groups[0]['lr'], clips / dt), flush=True)
+        if val_every and done % val_every == 0:
+            Tv, Hv = frames // gamma_tau, crop_size
+            vb = []
+            for _ in range(val_batches):
+                xv, yv = device_batch(val_batch_size * val_crops, Tv, Hv, 400, dev, gen)
+                vb.append((xv.view(val_batch_size, val_crops, 3, Tv, Hv, Hv), yv.view(-1)[:val_batch_size]))
+            v_loss, v_acc, v_seen = validate(model, vb)
+            model.train(True)                                   # train...:199-200
+            if rank == 0:
+                print(' val after step {}: Cls Loss: {:.4f} Acc: {:.4f} ({} videos)'.format(steps, v_loss, v_acc, v_seen), flush=True)
         if save_every and steps % save_every == 0 and rank == 0:
             ckpt = {'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict(),
                     'scheduler_state_dict': lr_sched.state_dict(), 'long_ind': long_ind}
