@@ -162,3 +162,32 @@ def test_batch_not_divisible_by_splits_raises():
     net.train(True)
     with pytest.raises(ValueError):
         net(torch.zeros(6, 3, 4, 32, 32, device=dev))
+
+
+def test_xl_widths_vs_oracle():
+    """X3D-XL (x3d.py:355: widths 24/48/96/192 x expansion, deeper stages, 630-channel bottlenecks): forward, loss and
+    gradient norms of the HIP path against the CPU oracle on identical inputs (tiny clip)."""
+    import x3d
+    dev = _dev()
+    S = 1
+    sd = synthetic.procedural_state_dict(xo.state_template("XL", 400, S), 2)
+    net = x3d.generate_model("XL", n_classes=400, dropout=0.0, base_bn_splits=S)
+    net.load_state_dict(sd)
+    net.to(dev).train(True)
+    x = synthetic.synthetic_clips(2, 4, 64, 64, seed=9)
+    y = synthetic.synthetic_labels(2, seed=9)
+    logits = net(x.to(dev))
+    loss = torch.nn.CrossEntropyLoss()(logits, y.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    lo, ls, go, _ = xo.train_step_grads(x, y, sd, "XL", S)
+    assert parity.rel(logits.detach().cpu().numpy(), lo.numpy()) < parity.RTOL
+    assert abs(loss.item() - ls.item()) / abs(ls.item()) < parity.RTOL
+    got = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    assert list(got.keys()) == list(go.keys())
+    gn = torch.sqrt(sum((v.double() ** 2).sum() for v in got.values()))
+    gr = torch.sqrt(sum((v.double() ** 2).sum() for v in go.values()))
+    assert abs(gn - gr) / gr < 2e-2          # two fp32 evaluations of a 1600-tensor BN/ReLU net at B=2 (see tests/parity.py on the noise floor)
+    big = [k for k, v in go.items() if v.numel() > 1000]
+    med = np.median([float((got[k].double() - go[k].double()).norm() / go[k].double().norm().clamp_min(1e-30)) for k in big])
+    assert med < 5e-2
