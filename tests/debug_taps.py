@@ -1,5 +1,5 @@
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "x3d-multigrid_amd"))
 import torch
 from oracle import x3d_oracle as xo
