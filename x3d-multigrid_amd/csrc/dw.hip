@@ -1,17 +1,22 @@
 // Channelwise 3x3x3 convolution (conv3x3x3, x3d.py:87-95; Bottleneck.conv2 x3d.py:114,150):
-// forward and a fused backward (data + weight).  HBM-bound (4.7 FLOP/B): every input voxel is
-// read from HBM once and every output voxel written once.
+// forward and a fused backward (data + weight).  Every input voxel is read from HBM once and
+// every output voxel written once (4.7 FLOP/B).
 //
 // Work decomposition: one workgroup owns CPB channels x one tile of TH rows (full width) of
-// one sample and marches along T.  A ring of four (T-plane) slots in LDS holds the
-// activated, zero-padded input rows (BN-apply + ReLU is applied while staging, so padding is
-// exact zero in the activated domain, as in nn.Conv3d(padding=1) on the ReLU output).
-// Plane t+2 is fetched into registers (float4, W-coalesced) before plane t is computed and
-// written to its slot afterwards: HBM latency hides under the stencil arithmetic, one
+// one sample and marches along T.  Two (T-plane) slots in LDS hold the activated, zero-padded
+// input rows (BN-apply + ReLU is applied while staging, so padding is exact zero in the
+// activated domain, as in nn.Conv3d(padding=1) on the ReLU output); every thread keeps the
+// three planes its stencil touches in a register window that slides along T, so each staged
+// value is read from LDS once.  Plane t+2 is requested (branch-free, clamped addresses) before
+// plane t is computed and written to its slot afterwards; the step's output store is issued
+// after that LDS write (no wait ever sits behind a fresh store on the single gfx9 vmcnt); one
 // barrier per plane.  Each thread produces 4 consecutive outputs along W per plane from
-// 9 LDS row reads (b128 + 2 b32); the 27 taps live in registers.
+// 9 LDS row reads; the 27 taps live in registers.
 // BN statistics (sum, sum of squares) are accumulated per thread across the whole T march
 // and leave as one partial per (sample, channel, tile).
+// Measured (profiles/r01/timelines.txt): stage 1-2 planes run near the HBM
+// roofline; on the 14x14 / 7x7 planes of stages 3-4 the kernels are bound by instruction issue
+// and per-step latency, not by bytes.
 #include "common.h"
 #include <map>
 #include <mutex>

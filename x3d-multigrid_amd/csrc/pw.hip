@@ -1,18 +1,22 @@
-// Pointwise (1x1x1) convolution kernels: fp32 MFMA GEMMs with fused prologues/epilogues.
+// Pointwise (1x1x1) convolution kernels: MFMA GEMMs with fused prologues/epilogues.
 //
 // Reference call sites replaced: conv1x1x1 (x3d.py:98-103) used as Bottleneck.conv1/conv3
 // (:112,116,146,162), downsample[0] (:272), conv5 (:231,327) and their autograd backward.
 //
-// Mapping (all three kernels): v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, the same
-// rounding as a VALU fmaf loop) with output channels on the MFMA row index and voxels on
-// the column index, so every lane owns 4 consecutive voxels of a channel row:
-//   - the B operand (activations, [C][P] row-major, P contiguous) is loaded straight from
-//     HBM as one float4 per lane: 16 lanes x 16 B = 256 B contiguous per channel row, four
-//     channel rows per wave instruction, no LDS round trip and no redundant loads;
-//   - the A operand (weights, tiny) is staged per 32-channel chunk in LDS as [m][34]
-//     (conflict-free ds_read_b32 for the 16x4 fragment);
-//   - the result is stored as float4 per lane (256 B contiguous per channel row).
-// BN statistics / BN-backward reductions ride in the epilogue: 16-lane DPP row sums, then
+// Kernels in this file (DESIGN.md 4.1 has the table):
+//   pw3_kernel        forward / data-gradient, stages 1-2: barrier-free streaming, activations straight
+//                     from HBM as one float4 (or dword) per lane, pre-packed weight fragments, fp32 MFMA
+//   pw4_kernel        forward, stages 3-4: persistent software-pipelined LDS-tiled GEMM, fp32 MFMA
+//   pw5_kernel        data-gradient, stages 3-4: pw4's pipeline on split-bf16 MFMA (hi+lo, 3 products)
+//   pw2_kernel, pw_kernel   fallbacks (P % 4 != 0, strided gather, no packed weights)
+//   pw_wgrad3_kernel  weight gradient, every dense shape: split-bf16 MFMA, LDS-tiled, XCD-aware groups
+//   pw_wgrad2_kernel, pw_wgrad_kernel   exact-fp32 / strided weight gradient
+//   pw_pack*_kernel   weights -> MFMA fragment order (fp32 image; transposed image also as bf16 hi/lo planes)
+// Common mapping: output channels on the MFMA row index, voxels on the column index, so every lane
+// owns consecutive voxels of a channel row and results are stored as float4 / float2 row segments.
+// Forward GEMMs are exact fp32 (v_mfma_f32_16x16x4_f32, the same rounding as a VALU fmaf chain); the
+// backward GEMMs use v_mfma_f32_16x16x32_bf16 on split operands (DESIGN.md 4.2 for why only there).
+// BN statistics / BN-backward reductions ride in the epilogues: 16-lane DPP row sums, then
 // one partial per (sample, channel, voxel tile) -- summed later in fixed order (fp64).
 #include <cstdlib>
 #include "common.h"
