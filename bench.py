@@ -61,7 +61,7 @@ class KernelTimer:
 
     def __enter__(self):
         for name in ("pw_fwd", "pw_bwd_data", "pw_bwd_weight", "dw333_fwd", "dw333_bwd", "stem133_fwd",
-                     "stem133_bwd_weight", "dw5t_fwd", "dw5t_bwd", "bn_add_relu_fwd", "bn_add_relu_bwd",
+                     "stem133_bwd_weight", "dw5t_fwd", "dw5t_bwd", "bn_add_relu_fwd", "bn_stats_add_relu_fwd", "bn_add_relu_bwd",
                      "bn_relu_pool_fwd", "bn_relu_pool_bwd", "bn_fwd_finalize", "bn_bwd_finalize", "se_fwd",
                      "se_bn_bwd_finalize", "sgd_fused"):
             fn = getattr(self.ops, name)
@@ -121,7 +121,7 @@ def _alg_bytes(name, a, k, r):
             return 4 * 2 * (n(a[0]) + n(a[4]))
         if name == "stem133_bwd_weight":
             return 4 * (n(a[0]) + n(a[1]))
-        if name in ("bn_add_relu_fwd", "bn_add_relu_bwd"):
+        if name in ("bn_add_relu_fwd", "bn_stats_add_relu_fwd", "bn_add_relu_bwd"):
             return 4 * 3 * n(a[0])
         if name in ("bn_relu_pool_fwd", "bn_relu_pool_bwd"):
             return 4 * n(a[0])

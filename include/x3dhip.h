@@ -215,6 +215,14 @@ int x3d_se_bn_bwd_finalize(const float* partial, int N, int C, int tiles, int S,
 int x3d_ew_tiles(int P);
 int x3d_bn_add_relu_fwd(const float* a3, const float* c3, const float* res, const float* cd,
                         float* out, int N, int C, int P, void* stream);
+/* Training form with BN3's finalize folded in: scale/shift are derived inside the kernel from conv3's
+ * statistics partials float[N][C][tiles][2] (x3d.py:47-58: per-(split, channel) mean / biased variance over
+ * N/S samples x count voxels, eps, running statistics with momentum and unbiased variance);
+ * save float[2][S][C] receives (mean, invstd) for the backward pass.  cd as above. */
+int x3d_bn_stats_add_relu_fwd(const float* a3, const float* partial, int tiles, int S, int count,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, float* save, const float* res, const float* cd,
+                              float* out, int N, int C, int P, void* stream);
 int x3d_bn_add_relu_bwd(const float* dout, const float* out, const float* a3, const float* ad,
                         float* g, float* partial, float* partial_d,
                         int N, int C, int P, void* stream);

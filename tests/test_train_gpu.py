@@ -151,7 +151,10 @@ def test_split_graph_backward_equals_single_graph(monkeypatch):
             loss, logits = tr.train_step(x, y)
         torch.cuda.synchronize()
         res.append((float(loss), tr.fp.grad.clone(), tr.fp.flat.clone(), int(model.state_dict()["bn1.split_bn.num_batches_tracked"])))
-    assert res[0][0] == res[1][0]
+    # the loss VALUE comes out of torch's cross-entropy reduction, which is not bitwise reproducible run to run on this
+    # stack (identical logits and gradients, last-bit differences in the scalar: tests/debug_determinism.py); everything
+    # produced by the HIP path -- gradients, updated weights -- must be bit-identical
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
     assert torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
     assert res[0][3] == res[1][3] == 2

@@ -472,6 +472,86 @@ __global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __res
     }
 }
 
+// Training form of the block output with the BN3 finalize folded in (one launch less per block on the forward chain,
+// where kernel times simply add up): every workgroup first requests its slice of a3 / residual, then reduces the
+// statistics of ITS (split, channel) from conv3's per-tile partials (N/S samples x tiles pairs, fp64, fixed order -- every
+// workgroup of a (split, channel) gets the identical value), derives scale / shift and applies them.  The workgroup with
+// blockIdx.x == 0 of the first sample of a split writes mean / invstd for the backward pass and the running statistics
+// (x3d.py:47-58, momentum 0.1, unbiased variance).
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_stats_add_relu_fwd_kernel(
+    const float* __restrict__ a3, const float* __restrict__ partial, int tiles, int N, int C, int S, int count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+    float momentum, float eps, float* __restrict__ save, const float* __restrict__ res, const float* __restrict__ cd,
+    float* __restrict__ out, int P) {
+    __shared__ double redd[4 * 2];
+    const int row = blockIdx.y, tid = threadIdx.x;
+    const int n = row / C, c = row - n * C, j = n % S;
+    const size_t base = (size_t)row * P;
+    const int p0 = blockIdx.x * EW_TILE;
+    // 1. the streaming reads do not depend on the statistics: issue them first
+    float4 av[2], rv[2];
+    if (VEC) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + (u * 256 + tid) * 4;
+            const int pc = p < P ? p : 0;
+            av[u] = *reinterpret_cast<const float4*>(a3 + base + pc);
+            rv[u] = *reinterpret_cast<const float4*>(res + base + pc);
+        }
+    }
+    // 2. statistics of (split j, channel c)
+    const int ns = N / S, ne = ns * tiles;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = tid; e < ne; e += 256) {
+        const int k = e / tiles, t = e - k * tiles;
+        const float2 v = *reinterpret_cast<const float2*>(partial + (((size_t)(j + k * S) * C + c) * tiles + t) * 2);
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { redd[(tid >> 6) * 2] = s1; redd[(tid >> 6) * 2 + 1] = s2; }
+    __syncthreads();
+    s1 = (redd[0] + redd[2]) + (redd[4] + redd[6]);
+    s2 = (redd[1] + redd[3]) + (redd[5] + redd[7]);
+    const double cnt = (double)count * (double)ns;
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * invstd);
+    const float sh = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+    if (blockIdx.x == 0 && n == j && tid == 0) {
+        save[(size_t)j * C + c] = (float)mean;
+        save[(size_t)(S + j) * C + c] = (float)invstd;
+        if (rmean != nullptr) {
+            const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            rmean[(size_t)j * C + c] = (float)((1.0 - momentum) * rmean[(size_t)j * C + c] + momentum * mean);
+            rvar[(size_t)j * C + c] = (float)((1.0 - momentum) * rvar[(size_t)j * C + c] + momentum * unb);
+        }
+    }
+    float rc = 1.f, rh = 0.f;
+    if (cd != nullptr) { rc = cd[(size_t)row * 2]; rh = cd[(size_t)row * 2 + 1]; }
+    // 3. elementwise
+    if (VEC) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + (u * 256 + tid) * 4;
+            if (p < P) {
+                float4 o;
+                o.x = fmaxf(fmaf(sc, av[u].x, sh) + fmaf(rc, rv[u].x, rh), 0.f);
+                o.y = fmaxf(fmaf(sc, av[u].y, sh) + fmaf(rc, rv[u].y, rh), 0.f);
+                o.z = fmaxf(fmaf(sc, av[u].z, sh) + fmaf(rc, rv[u].z, rh), 0.f);
+                o.w = fmaxf(fmaf(sc, av[u].w, sh) + fmaf(rc, rv[u].w, rh), 0.f);
+                *reinterpret_cast<float4*>(out + base + p) = o;
+            }
+        }
+    } else {
+        for (int p = p0 + tid; p < min(P, p0 + EW_TILE); p += 256)
+            out[base + p] = fmaxf(fmaf(sc, a3[base + p], sh) + fmaf(rc, res[base + p], rh), 0.f);
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                               const float* __restrict__ a3, const float* __restrict__ ad,
@@ -685,6 +765,24 @@ extern "C" int x3d_bn_add_relu_fwd(const float* a3, const float* c3, const float
         hipLaunchKernelGGL(bn_add_relu_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a3, c3, res, cd, out, P);
     else
         hipLaunchKernelGGL(bn_add_relu_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a3, c3, res, cd, out, P);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_bn_stats_add_relu_fwd(const float* a3, const float* partial, int tiles, int S, int count,
+                                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                         float momentum, float eps, float* save, const float* res, const float* cd,
+                                         float* out, int N, int C, int P, void* stream) {
+    X3D_CHECK_ARG(a3 && partial && gamma && beta && save && res && out && N > 0 && C > 0 && P > 0 && tiles > 0);
+    X3D_CHECK_ARG(S > 0 && N % S == 0 && count > 0 && N * C <= 65535);
+    X3D_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+    dim3 grid(cdiv(P, EW_TILE), N * C), block(256);
+    if (P % 4 == 0)
+        hipLaunchKernelGGL(bn_stats_add_relu_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a3, partial, tiles, N, C,
+                           S, count, gamma, beta, running_mean, running_var, momentum, eps, save, res, cd, out, P);
+    else
+        hipLaunchKernelGGL(bn_stats_add_relu_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a3, partial, tiles, N, C,
+                           S, count, gamma, beta, running_mean, running_var, momentum, eps, save, res, cd, out, P);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

@@ -199,10 +199,9 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx, packs):
     else:
         c2e = c2
     a3, p3 = ops.pw_fwd(a2, w3, pre=c2e, pre_act=ACT_SWISH, want_stats=training, wp=packs.get(blk.conv3.weight))
-    if training:
-        c3, s3, _ = _bn_train(p3, blk.bn3, S, P2)
-    else:
-        c3, s3 = _bn_eval(blk.bn3, N), None
+    c3 = s3 = None
+    if not training:
+        c3 = _bn_eval(blk.bn3, N)           # training: BN3's finalize is folded into the block-output kernel below
     ad = cd = sd = None
     if blk.downsample is not None:
         wd = _w2d(blk.downsample[0].weight)
@@ -212,11 +211,17 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx, packs):
             cd, sd, _ = _bn_train(pd, blk.downsample[1], S, P2)
         else:
             cd, sd = _bn_eval(blk.downsample[1], N), None
-        out = ops.bn_add_relu_fwd(a3, c3, ad, cd)
+        res, rcoef = ad, cd
     else:
         if x_coef is not None:
             raise RuntimeError("identity residual needs a materialised block input")
-        out = ops.bn_add_relu_fwd(a3, c3, x_raw, None)
+        res, rcoef = x_raw, None
+    if training:
+        bn3 = blk.bn3
+        out, s3 = ops.bn_stats_add_relu_fwd(a3, p3, S, P2, bn3.weight.data, bn3.bias.data, bn3.split_bn.running_mean,
+                                            bn3.split_bn.running_var, res, rcoef, momentum=BN_MOMENTUM, eps=BN_EPS)
+    else:
+        out = ops.bn_add_relu_fwd(a3, c3, res, rcoef)
     if ctx is not None:
         # transposed packs for the backward-data GEMMs (weights are unchanged until the optimizer step)
         ctx.blocks.append(dict(blk=blk, x_raw=x_raw, x_coef=x_coef, a1=a1, c1=c1, s1=s1, a2=a2, c2e=c2e, s2=s2,

@@ -270,6 +270,22 @@ def bn_add_relu_fwd(a3, c3, res, cd=None, out=None):
     return o
 
 
+def bn_stats_add_relu_fwd(a3, partial, S, count, gamma, beta, running_mean, running_var, res, cd=None, momentum=0.1,
+                          eps=1e-5, out=None):
+    """Block output in training with BN3's finalize folded in.  Returns (out, save[2, S, C])."""
+    _need_cuda(a3, partial, res, cd)
+    L = _lib.lib()
+    N, C = a3.shape[:2]
+    P = a3[0, 0].numel()
+    tiles = partial.shape[2]
+    o = out if out is not None else _f(a3.shape, a3)
+    save = _f((2, S, C), a3)
+    check(L.x3d_bn_stats_add_relu_fwd(ptr(a3), ptr(partial), tiles, S, count, ptr(gamma), ptr(beta), ptr(running_mean),
+                                      ptr(running_var), momentum, eps, ptr(save), ptr(res), ptr(cd), ptr(o), N, C, P,
+                                      _lib.stream()))
+    return o, save
+
+
 def bn_add_relu_bwd(dout, out, a3, ad=None, g=None):
     _need_cuda(dout, out, a3, ad)
     L = _lib.lib()
