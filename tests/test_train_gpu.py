@@ -158,3 +158,25 @@ def test_split_graph_backward_equals_single_graph(monkeypatch):
     assert torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
     assert res[0][3] == res[1][3] == 2
+
+
+def test_training_reduces_loss_on_a_fixed_batch():
+    """End-to-end sanity of the whole step (forward, backward, split-precision GEMMs, fused SGD, BN running stats,
+    hipGraph replay): 40 steps on one fixed synthetic batch must drive the loss far below log(400) = 5.99."""
+    import x3d as resnet_x3d
+    from x3dhip import synthetic
+    from x3dhip.trainer import Trainer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=1).to(dev).train(True)
+    tr = Trainer(model, lr=0.02, momentum=0.9, weight_decay=5e-5, use_graph=True)
+    x = synthetic.synthetic_clips(8, 4, 64, 64, seed=3).to(dev)
+    y = synthetic.synthetic_labels(8, seed=3).to(dev)
+    losses = []
+    for _ in range(40):
+        loss, logits = tr.train_step(x, y)
+        losses.append(float(loss))
+    assert all(l == l for l in losses), "NaN in the loss"
+    assert losses[0] > 4.5 and losses[-1] < 0.5 * losses[0], losses[::8]
+    acc = float((logits.argmax(1) == y).float().mean())
+    assert acc >= 0.75, (acc, losses[::8])
