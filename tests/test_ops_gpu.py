@@ -61,6 +61,8 @@ PW_CASES = [
     (1, 70, 98, 2, 6, 6, 1, 0),       # LDS-tiled, K % 4 != 0 (scalar weight staging)
     (20, 96, 112, 8, 14, 14, 1, 2),   # persistent tiled kernel: 800 items > grid (2 items per workgroup), 7 M-tiles (U = 4)
     (20, 128, 96, 4, 16, 16, 1, 1),   # persistent tiled kernel: 4 chunks per item, 6 M-tiles (U = 3), item list with a tail
+    (2, 48, 96, 4, 16, 16, 2, 1),     # stride 2 with P_out % 4 == 0: gathered-input weight-gradient kernel (downsample branch)
+    (3, 24, 24, 2, 12, 20, 2, 0),     # same, narrow channels (64 x 32 tile), raw input
 ]
 
 

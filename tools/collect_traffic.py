@@ -9,10 +9,11 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
-FAMILY = [("pw_wgrad", "pw_bwd_weight"), ("pw5_kernel", "pw"), ("pw4_kernel", "pw"), ("pw2_kernel", "pw"), ("pw3_kernel", "pw"), ("pw_kernel", "pw"),
-          ("dw_fwd_kernel", "dw333_fwd"), ("dw_bwd_kernel", "dw333_bwd"), ("bn_add_relu_fwd", "bn_add_relu_fwd"),
+FAMILY = [("pw_wgrad", "pw_bwd_weight"),
+          ("dw_fwd_kernel", "dw333_fwd"), ("dw_bwd_kernel", "dw333_bwd"), ("bn_stats_add_relu_fwd", "bn_stats_add_relu_fwd"), ("bn_add_relu_fwd", "bn_add_relu_fwd"),
           ("bn_add_relu_bwd", "bn_add_relu_bwd"), ("dw5t_fwd", "dw5t_fwd"), ("dw5t_bwd", "dw5t_bwd"),
           ("stem133_fwd", "stem133_fwd"), ("stem133_wgrad", "stem133_bwd_weight")]
 
@@ -36,6 +37,17 @@ def load(d, counter):
 
 
 def fam(name):
+    """bench.py op family of a kernel name.  Pointwise forward and data-gradient share kernel templates: the input-mode
+    template argument tells them apart (IN = 2 is the BN-backward prologue of the data gradient)."""
+    m = re.search(r"pw5_kernel", name)
+    if m:
+        return "pw_bwd_data"
+    m = re.search(r"pw4_kernel<(\d+)", name) or re.search(r"pw2_kernel<(\d+)", name)
+    if m:
+        return "pw_bwd_data" if m.group(1) == "2" else "pw_fwd"
+    m = re.search(r"pw3_kernel<\d+, \d+, (\d+)", name) or re.search(r"::pw_kernel<\d+, \d+, (\d+)", name)
+    if m:
+        return "pw_bwd_data" if m.group(1) == "2" else "pw_fwd"
     for key, f in FAMILY:
         if key in name:
             return f
@@ -58,10 +70,6 @@ def main():
     for f, (rd, wr, n) in agg.items():
         out[f] = {"launches": n, "hbm_read_bytes_per_launch": rd / max(n, 1), "hbm_write_bytes_per_launch": wr / max(n, 1),
                   "hbm_bytes_per_launch": (rd + wr) / max(n, 1)}
-    # the bench's op families split pw into fwd / bwd_data: report the pooled pw figure under both
-    if "pw" in out:
-        out["pw_fwd"] = out["pw"]
-        out["pw_bwd_data"] = out["pw"]
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for f, v in sorted(out.items()):
         print("%-20s launches %5d  read %10.1f MB  write %10.1f MB per launch" %

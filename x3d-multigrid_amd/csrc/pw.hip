@@ -1881,7 +1881,9 @@ __device__ __forceinline__ void split_bf16x4(const float (&v)[4], bf16x4& hi, bf
 
 // CO x CI = output tile of a workgroup (dY channels x input channels): 128 x 64 for the wide layers, 64-row and
 // 32-column variants for the narrow ones (stages 1-2) so that padding rows are not staged for nothing.
-template <int CO, int CI>
+// GATHER: the input of a stride-(1,2,2) convolution (the downsample branch): its four voxels per slot are read at
+// (t, 2 ho, 2 wo) of the full-resolution input instead of as one float4.
+template <int CO, int CI, bool GATHER>
 __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
     constexpr int ND = CO / 16, NX = CI / 16;            // staged float4 slots per thread (dY, input)
     constexpr int MW = CO / 64, NW = CI / 16;            // 16x16 tiles per wave: MW (dY) x NW (input)
@@ -1918,10 +1920,23 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
             const float* cb = A.cb + ((size_t)n * A.Co + co) * 3;
             k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
         }
+        int goff[4] = {0, 0, 0, 0};
+        if (GATHER) {                                    // input offsets of this slot's four output voxels (row independent)
+            const int hw = A.Ho * A.Wo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int p = pc + e;
+                const int t = p / hw, rem = p - t * hw;
+                const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
+                goff[e] = (t * A.H + 2 * ho) * A.W + 2 * wo;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int ci = min(ci0 + row0 + 16 * i, A.Ci - 1);
-            rx[i] = *reinterpret_cast<const float4*>(A.x + ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc);
+            const float* px = A.x + ((size_t)n * A.Ci + ci) * (size_t)A.Pin;
+            if (GATHER) rx[i] = make_float4(px[goff[0]], px[goff[1]], px[goff[2]], px[goff[3]]);
+            else rx[i] = *reinterpret_cast<const float4*>(px + pc);
             if (A.pre != nullptr) {
                 const float2 p2 = *reinterpret_cast<const float2*>(A.pre + ((size_t)n * A.Ci + ci) * 2);
                 sc[i] = p2.x; sh[i] = p2.y;
@@ -2022,7 +2037,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
 }
 
 static bool wgrad2_ok(int P, long long Pin, int Co, int Ci, bool strided) {
-    return !strided && (P % 4 == 0) && (Pin % 4 == 0);
+    if (strided) return (P % 4 == 0) && getenv("X3D_WGRAD_F32") == nullptr;    // gathered input: split-bf16 kernel only
+    return (P % 4 == 0) && (Pin % 4 == 0);
 }
 // workgroup tile of the split-bf16 kernel for a Co x Ci weight
 static int wg3_co(int Co) { return Co > 64 ? 128 : 64; }
@@ -2188,12 +2204,20 @@ extern "C" int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb
         hipStream_t s3 = (hipStream_t)stream;
         if (getenv("X3D_WGRAD_F32") != nullptr) {
             hipLaunchKernelGGL(pw_wgrad2_kernel, grid, block, 0, s3, A);
+        } else if (A.strided) {
+            if (wg3_co(Cout) == 128) {
+                if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<128, 64, true>), grid, block, 0, s3, A);
+                else hipLaunchKernelGGL((pw_wgrad3_kernel<128, 32, true>), grid, block, 0, s3, A);
+            } else {
+                if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<64, 64, true>), grid, block, 0, s3, A);
+                else hipLaunchKernelGGL((pw_wgrad3_kernel<64, 32, true>), grid, block, 0, s3, A);
+            }
         } else if (wg3_co(Cout) == 128) {
-            if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<128, 64>), grid, block, 0, s3, A);
-            else hipLaunchKernelGGL((pw_wgrad3_kernel<128, 32>), grid, block, 0, s3, A);
+            if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<128, 64, false>), grid, block, 0, s3, A);
+            else hipLaunchKernelGGL((pw_wgrad3_kernel<128, 32, false>), grid, block, 0, s3, A);
         } else {
-            if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<64, 64>), grid, block, 0, s3, A);
-            else hipLaunchKernelGGL((pw_wgrad3_kernel<64, 32>), grid, block, 0, s3, A);
+            if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<64, 64, false>), grid, block, 0, s3, A);
+            else hipLaunchKernelGGL((pw_wgrad3_kernel<64, 32, false>), grid, block, 0, s3, A);
         }
         X3D_LAUNCH_CHECK();
         return X3D_OK;
