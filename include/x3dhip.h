@@ -124,6 +124,16 @@ int x3d_dw333_fwd(const float* x, const float* w, float* y,
                   int N, int C, int T, int H, int W, int strideHW,
                   const float* pre, int pre_act, float* partial, void* stream);
 
+/* Training form with the producer BN's finalize folded in (one launch less per block): the scale / shift applied while
+ * loading x are derived inside the kernel from the producer conv's statistics partials
+ * spartial float[N][C][stiles][2] (x3d.py:47-58; S splits, `count` voxels per (n, c), eps, running statistics with
+ * momentum / unbiased variance).  coef_out float[N][C][2] and save float[2][S][C] (mean, invstd) are written for the
+ * backward pass. */
+int x3d_dw333_fwd_stats(const float* x, const float* w, float* y, int N, int C, int T, int H, int W, int strideHW,
+                        const float* spartial, int stiles, int S, int count, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* save,
+                        float* coef_out, int pre_act, float* partial, void* stream);
+
 /* Fused backward (data + weight) of the conv above:
  *   dY = cb0*g + cb1*a + cb2 (g,a at output resolution [N,C,T,Ho,Wo])
  *   hin = act(pre*x+pre)  (x raw [N,C,T,H,W])

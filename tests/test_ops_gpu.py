@@ -196,6 +196,37 @@ def test_dw333_fwd_bwd(case):
     assert _rel(st[..., 1], (out_ref * x).sum(dim=(2, 3, 4))) < 1e-4
 
 
+@pytest.mark.parametrize("case", DW_CASES)
+@pytest.mark.parametrize("S", [1, 2])
+def test_dw333_fwd_stats_equals_finalize_then_conv(case, S):
+    """The training form with bn1's finalize folded into the depthwise prologue equals bn_fwd_finalize + dw333_fwd:
+    coefficients / saved statistics / running statistics to fp64-reorder noise, the conv output to fp32 rounding."""
+    from x3dhip import ops
+    dev = _dev()
+    N, C, T, H, W, s = case
+    if N % S:
+        pytest.skip("batch not divisible by the split count")
+    x = _g(N, C, T, H, W, seed=1).float().to(dev)
+    w = (_g(C, 1, 3, 3, 3, seed=2) / 3).float().to(dev)
+    P = T * H * W
+    for stiles in (1, 7, 200):
+        sp = torch.stack([_g(N, C, stiles, seed=11) * 3, 50 + _g(N, C, stiles, seed=12).abs() * 40], -1).float().to(dev)
+        gamma = (1 + 0.2 * _g(C, seed=13)).float().to(dev)
+        beta = (0.3 * _g(C, seed=14)).float().to(dev)
+        rm0 = (0.1 * _g(S, C, seed=15)).float().to(dev)
+        rv0 = (1 + 0.1 * _g(S, C, seed=16).abs()).float().to(dev)
+        rm_a, rv_a, rm_b, rv_b = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
+        coef, save, _ = ops.bn_fwd_finalize(sp, S, P, gamma, beta, rm_a, rv_a, 0.1, 1e-5)
+        y_ref, p_ref = ops.dw333_fwd(x, w, stride=s, pre=coef, pre_act=1)
+        y, part, coef2, save2 = ops.dw333_fwd_stats(x, w, sp, S, P, gamma, beta, rm_b, rv_b, stride=s, pre_act=1,
+                                                    momentum=0.1, eps=1e-5)
+        assert _rel(coef2, coef) < 1e-6
+        assert _rel(save2, save) < 1e-6
+        assert _rel(rm_b, rm_a) < 1e-6 and _rel(rv_b, rv_a) < 1e-6
+        assert _rel(y, y_ref) < 1e-5
+        assert _rel(part.double().sum(2), p_ref.double().sum(2)) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 4, 16, 16), (1, 3, 3, 15, 11), (1, 3, 2, 64, 64)])
 def test_stem(shape):
     from x3dhip import ops

@@ -66,6 +66,11 @@ static DwGeom make_geom(int N, int C, int T, int H, int W, int stride, bool back
 struct DwFwdArgs {
     const float* x; const float* w; float* y; const float* pre; int pre_act; float* partial;
     DwGeom g;
+    // training form: the producer BN's finalize is folded into this kernel (sp != NULL, pre == NULL): the scale / shift of
+    // the workgroup's channels are derived from the producer conv's statistics partials sp[N][C][stiles][2]
+    const float* sp; int stiles, S, count;
+    const float* gamma; const float* beta; float* rmean; float* rvar; float momentum, eps;
+    float* save; float* coef_out;
 };
 
 // Per-thread descriptor of one staged float4 chunk; everything that does not depend on t is
@@ -191,8 +196,71 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     const int plane = g.H * g.W;
 
     float4 reg[NCH];
-    __syncthreads();
-    fetch4<NCH, VEC>(xb, ch, 0, true, reg);
+    fetch4<NCH, VEC>(xb, ch, 0, true, reg);              // needs addresses only: in flight during the statistics below
+    if (A.sp != nullptr) {
+        // BN finalize of this workgroup's channels for sample n's split (x3d.py:47-58): fp64 sums over N/S samples x
+        // stiles partial pairs in a fixed order (identical in every workgroup of a (split, channel)); the tile-0
+        // workgroup publishes the per-(n, c) coefficients for the backward pass, the one of the split's first sample
+        // also mean / invstd and the running statistics.
+        __shared__ double dred[16 * 4 * 2];
+        __shared__ float lcoef[16 * 2];
+        const int lane = tid & 63, wave = tid >> 6;
+        const int j = n % A.S, ns = g.N / A.S, ne = ns * A.stiles;
+        const int wpc = g.cpb == 1 ? 4 : (g.cpb == 2 ? 2 : 1), cpp = 4 / wpc;    // waves per channel, channels per pass
+        for (int cb0 = 0; cb0 < g.cpb; cb0 += cpp) {
+            const int ccs = cb0 + wave / wpc, sub = wave % wpc;
+            if (ccs < g.cpb) {
+                const int cg = min(c0 + ccs, g.C - 1);
+                double s1 = 0.0, s2 = 0.0;
+                for (int e = sub * 64 + lane; e < ne; e += 64 * wpc) {
+                    const int k = e / A.stiles, t = e - k * A.stiles;
+                    const float2 v = *reinterpret_cast<const float2*>(A.sp + (((size_t)(j + k * A.S) * g.C + cg) * A.stiles + t) * 2);
+                    s1 += (double)v.x;
+                    s2 += (double)v.y;
+                }
+                for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                if (lane == 0) { dred[(ccs * 4 + sub) * 2] = s1; dred[(ccs * 4 + sub) * 2 + 1] = s2; }
+            }
+        }
+        __syncthreads();
+        if (tid < g.cpb) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int u = 0; u < wpc; ++u) { s1 += dred[(tid * 4 + u) * 2]; s2 += dred[(tid * 4 + u) * 2 + 1]; }
+            const int cg = min(c0 + tid, g.C - 1);
+            const double cnt = (double)A.count * (double)ns;
+            const double mean = s1 / cnt;
+            double var = s2 / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double invstd = 1.0 / sqrt(var + (double)A.eps);
+            const float scv = (float)((double)A.gamma[cg] * invstd);
+            const float shv = (float)((double)A.beta[cg] - mean * (double)A.gamma[cg] * invstd);
+            lcoef[tid * 2] = scv;
+            lcoef[tid * 2 + 1] = shv;
+            if (tile == 0 && c0 + tid < g.C) {
+                A.coef_out[((size_t)n * g.C + cg) * 2] = scv;
+                A.coef_out[((size_t)n * g.C + cg) * 2 + 1] = shv;
+                if (n == j) {
+                    A.save[(size_t)j * g.C + cg] = (float)mean;
+                    A.save[(size_t)(A.S + j) * g.C + cg] = (float)invstd;
+                    if (A.rmean != nullptr) {
+                        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+                        A.rmean[(size_t)j * g.C + cg] = (float)((1.0 - A.momentum) * A.rmean[(size_t)j * g.C + cg] + A.momentum * mean);
+                        A.rvar[(size_t)j * g.C + cg] = (float)((1.0 - A.momentum) * A.rvar[(size_t)j * g.C + cg] + A.momentum * unb);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int chsz = g.IH * g.WP;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ci = ch[i].loff >= 0 ? ch[i].loff / chsz : 0;
+            ch[i].sc = lcoef[ci * 2];
+            ch[i].sh = lcoef[ci * 2 + 1];
+        }
+    } else {
+        __syncthreads();
+    }
     store_act<NCH, VEC>(ring, ch, true, A.pre_act, reg);
     fetch4<NCH, VEC>(xb, ch, plane, g.T > 1, reg);
     store_act<NCH, VEC>(ring + g.slot, ch, g.T > 1, A.pre_act, reg);
@@ -631,7 +699,32 @@ extern "C" int x3d_dw333_fwd(const float* x, const float* w, float* y, int N, in
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
     DwFwdArgs A;
     A.x = x; A.w = w; A.y = y; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE; A.partial = partial;
+    A.sp = nullptr; A.stiles = 0; A.S = 1; A.count = 0; A.gamma = A.beta = nullptr; A.rmean = A.rvar = nullptr;
+    A.momentum = A.eps = 0.f; A.save = A.coef_out = nullptr;
     A.g = make_geom(N, C, T, H, W, strideHW, false);
+    const size_t ldsb = fwd_lds_bytes(A.g);
+    if (ldsb > 160 * 1024) { x3d_set_error("dw333_fwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    DW_DISPATCH(dw_fwd_kernel, A, A.g, ldsb);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_dw333_fwd_stats(const float* x, const float* w, float* y, int N, int C, int T, int H, int W,
+                                   int strideHW, const float* spartial, int stiles, int S, int count,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, float* save, float* coef_out, int pre_act,
+                                   float* partial, void* stream) {
+    X3D_CHECK_ARG(x && w && y && spartial && gamma && beta && save && coef_out);
+    X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0 && stiles > 0 && count > 0);
+    X3D_CHECK_ARG(S > 0 && N % S == 0 && (strideHW == 1 || strideHW == 2));
+    X3D_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+    DwFwdArgs A;
+    A.x = x; A.w = w; A.y = y; A.pre = nullptr; A.pre_act = pre_act; A.partial = partial;
+    A.g = make_geom(N, C, T, H, W, strideHW, false);
+    A.sp = spartial; A.stiles = stiles; A.S = S; A.count = count; A.gamma = gamma; A.beta = beta;
+    A.rmean = running_mean; A.rvar = running_var; A.momentum = momentum; A.eps = eps; A.save = save; A.coef_out = coef_out;
+    X3D_CHECK_ARG(A.g.cpb <= 16);
     const size_t ldsb = fwd_lds_bytes(A.g);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_fwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;

@@ -23,6 +23,7 @@ _Z = ctypes.c_size_t
 # tests/test_abi.py checks the two against each other.
 SIGNATURES = {
     "x3d_abi_version": (_I, []),
+    "x3d_dw333_fwd_stats": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P, _P]),
     "x3d_bn_stats_add_relu_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "x3d_clip_job_bytes": (_Z, []),
     "x3d_clip_preprocess": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),

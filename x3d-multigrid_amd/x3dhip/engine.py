@@ -17,6 +17,8 @@ touched the minimum number of times:
 
 Only raw conv outputs (a1, a2, a3, ad) and block outputs are kept for backward.
 """
+import os
+
 import torch
 
 from . import ops
@@ -120,6 +122,9 @@ class TrunkContext:
         self.head = None
 
 
+_NO_DW_STATS = os.environ.get("X3D_NO_DW_STATS", "0") == "1"
+
+
 def _bn_train(partial, bn, S, count, want_nsum=False):
     return ops.bn_fwd_finalize(partial, S, count, bn.weight.data, bn.bias.data,
                                bn.split_bn.running_mean, bn.split_bn.running_var,
@@ -177,12 +182,18 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx, packs):
     w1, w3 = _w2d(blk.conv1.weight), _w2d(blk.conv3.weight)
     a1, p1 = ops.pw_fwd(x_raw, w1, pre=x_coef, pre_act=pre_act, want_stats=training, wp=packs.get(blk.conv1.weight))
     P1 = a1[0, 0].numel()
-    if training:
-        c1, s1, _ = _bn_train(p1, blk.bn1, S, P1)
+    if training and not _NO_DW_STATS:
+        # bn1's finalize runs inside the depthwise kernel's prologue (one launch less per block)
+        a2, p2, c1, s1 = ops.dw333_fwd_stats(a1, blk.conv2.weight.data, p1, S, P1, blk.bn1.weight.data, blk.bn1.bias.data,
+                                             blk.bn1.split_bn.running_mean, blk.bn1.split_bn.running_var,
+                                             stride=stride, pre_act=ACT_RELU, momentum=BN_MOMENTUM, eps=BN_EPS)
     else:
-        c1, s1 = _bn_eval(blk.bn1, N), None
-    a2, p2 = ops.dw333_fwd(a1, blk.conv2.weight.data, stride=stride, pre=c1, pre_act=ACT_RELU,
-                           want_stats=training or blk.has_se)
+        if training:
+            c1, s1, _ = _bn_train(p1, blk.bn1, S, P1)
+        else:
+            c1, s1 = _bn_eval(blk.bn1, N), None
+        a2, p2 = ops.dw333_fwd(a1, blk.conv2.weight.data, stride=stride, pre=c1, pre_act=ACT_RELU,
+                               want_stats=training or blk.has_se)
     P2 = a2[0, 0].numel()
     nsum2 = None
     if training:

@@ -124,6 +124,23 @@ def dw333_fwd(x, w, stride=1, pre=None, pre_act=ACT_RELU, want_stats=True, out=N
     return y, (partial if want_stats else None)
 
 
+def dw333_fwd_stats(x, w, spartial, S, count, gamma, beta, running_mean, running_var, stride=1, pre_act=ACT_RELU,
+                    momentum=0.1, eps=1e-5):
+    """dw333_fwd in training with the producer BN's finalize folded in.  Returns (y, partial, coef[N,C,2], save[2,S,C])."""
+    _need_cuda(x, w, spartial)
+    L = _lib.lib()
+    N, C, T, H, W = x.shape
+    Ho, Wo = out_hw(H, stride), out_hw(W, stride)
+    y = _f((N, C, T, Ho, Wo), x)
+    partial = _f((N, C, L.x3d_dw_tiles(Ho, Wo), 2), x)
+    coef = _f((N, C, 2), x)
+    save = _f((2, S, C), x)
+    check(L.x3d_dw333_fwd_stats(ptr(x), ptr(w), ptr(y), N, C, T, H, W, stride, ptr(spartial), spartial.shape[2], S, count,
+                                ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), momentum, eps, ptr(save),
+                                ptr(coef), pre_act, ptr(partial), _lib.stream()))
+    return y, partial, coef, save
+
+
 def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wpartial=None, partial=None,
               dw_out=None, reduce=True):
     """reduce=False: returns (out, wpartial, partial) and leaves the [N*tiles] -> 1 group sum of the weight-gradient
