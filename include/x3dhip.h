@@ -101,6 +101,16 @@ int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float
                     const float* addend, int addend_stride,
                     float* partial, void* stream);
 
+/* The same data gradient with the residual-add + ReLU backward of the block that PRODUCED this conv's input folded into
+ * the epilogue (x3d.py:165-169 backward; what x3d_bn_add_relu_bwd does in a launch of its own for blocks without a
+ * downsample branch):
+ *   out[ci,p] = (dIn[ci,p] + addend) where res_out[ci,p] > 0, else 0      (= g3 of that block)
+ *   partial   = per-(n,ci,tile) {sum out, sum out*res_raw}                 (its bn3 backward statistics)
+ * res_out = that block's output [N,Cin,T,H,W], res_raw = its raw conv3 output. */
+int x3d_pw_bwd_data_res(const float* g, const float* a, const float* cb, const float* w, const float* wpacked_t,
+                        float* out, int N, int Cin, int Cout, int T, int H, int W, const float* res_out,
+                        const float* res_raw, const float* addend, int addend_stride, float* partial, void* stream);
+
 /* Backward-weight: dW[co,ci] = sum_{n,p} dY[co,p] * in[ci,p] with dY and in formed as above
  * (strideHW 2: in is sampled at even (h,w) of x[N,Cin,T,H,W]; g,a are at output resolution).
  * wpartial is float[x3d_pw_wgrad_groups(...)][Cout][Cin]; x3d_reduce_partials sums it. */

@@ -134,6 +134,40 @@ def test_pw_bwd(case):
         assert _rel(out, F.conv_transpose3d(dY, w.view(Co, Ci, 1, 1, 1))) < TOL
 
 
+@pytest.mark.parametrize("case", [c for c in PW_CASES if c[6] == 1])
+def test_pw_bwd_data_res(case):
+    """Data gradient with the producer block's residual-add + ReLU backward in the epilogue (every kernel variant the
+    planner picks for these shapes, with and without packed weights, dense and stride-2 addend)."""
+    from x3dhip import ops
+    dev = _dev()
+    N, Ci, Co, T, H, W, s, act = case
+    w = _g(Co, Ci, seed=2) / np.sqrt(Ci)
+    g = _g(N, Co, T, H, W, seed=5)
+    a = _g(N, Co, T, H, W, seed=6)
+    cb = torch.stack([1 + 0.1 * _g(N, Co, seed=7), 0.1 * _g(N, Co, seed=8), 0.05 * _g(N, Co, seed=9)], -1)
+    dY = cb[..., 0, None, None, None] * g + cb[..., 1, None, None, None] * a + cb[..., 2, None, None, None]
+    din = F.conv_transpose3d(dY, w.view(Co, Ci, 1, 1, 1))
+    res_out = torch.relu(_g(N, Ci, T, H, W, seed=12))          # the producer block's output (about half zeros)
+    res_raw = _g(N, Ci, T, H, W, seed=13)                       # its raw conv3 output
+    addend = _g(N, Ci, T, H, W, seed=10)
+    H2, W2 = xo.out_hw(H, 2), xo.out_hw(W, 2)
+    add2 = _g(N, Ci, T, H2, W2, seed=11)
+    full = torch.zeros(N, Ci, T, H, W, dtype=torch.float64)
+    full[:, :, :, ::2, ::2] = add2
+    to = lambda t: None if t is None else t.float().contiguous().to(dev)
+    mask = (res_out > 0).double()
+    for wpt in (None, ops.pw_pack(to(w), transposed=True)):
+        for add, astride, ref in ((None, 1, din), (addend, 1, din + addend), (add2, 2, din + full)):
+            ref = ref * mask
+            out, partial = ops.pw_bwd_data_res(to(g), to(a), to(cb), to(w), to(res_out), to(res_raw), addend=to(add),
+                                               addend_stride=astride, wpt=wpt)
+            assert _rel(out, ref) < TOL
+            assert bool((out.cpu()[mask == 0] == 0).all())
+            st = partial.double().sum(2).cpu()
+            assert _rel(st[..., 0], ref.sum(dim=(2, 3, 4))) < 1e-4
+            assert _rel(st[..., 1], (ref * res_raw).sum(dim=(2, 3, 4))) < 1e-4
+
+
 DW_CASES = [
     # N, C, T, H, W, stride
     (2, 6, 4, 14, 14, 1),

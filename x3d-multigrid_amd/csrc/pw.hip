@@ -24,7 +24,11 @@
 namespace {
 
 enum { IN_RAW = 0, IN_AFFACT = 1, IN_BNBWD = 2 };
-enum { EPI_STATS = 0, EPI_PLAIN = 1, EPI_ACTBWD = 2 };
+// EPI_RESBWD: the residual-add + ReLU backward of the block that produced this conv's input, folded into the data
+// gradient's epilogue:  y = (acc + addend) where emask > 0 else 0;  statistics sum(y), sum(y * ex)  (ex = that block's raw
+// conv3 output, emask = its output) -- what bn_add_relu_bwd computes in a launch of its own (x3d.py:165-169 backward).
+enum { EPI_STATS = 0, EPI_PLAIN = 1, EPI_ACTBWD = 2, EPI_RESBWD = 3 };
+#define EPI_HAS_X(E) ((E) == EPI_ACTBWD || (E) == EPI_RESBWD)
 constexpr int PW_MAXK = 640;   // per-sample input-coefficient table in LDS (XL: 630 channels)
 
 
@@ -45,6 +49,7 @@ struct PwArgs {
     int tiles;
     const float* ex;      // EPI_ACTBWD: raw x [N][M][P]
     const float* ecoef;   // EPI_ACTBWD: [N][M][2]
+    const float* emask;   // EPI_RESBWD: [N][M][P], gradient passes where emask > 0 (ex is then the statistics' multiplier)
     int e_act;
     const float* addend;  // EPI_PLAIN / EPI_ACTBWD (may be NULL)
     int addend_stride;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs A) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (mt < mt_run) {
-            float xv[4][NT], adv[4][NT], esc[4], esh[4];
+            float xv[4][NT], mk[4][NT], adv[4][NT], esc[4], esh[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = mt * 16 + 4 * q + e;
@@ -246,8 +251,9 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs A) {
                 if (EPI == EPI_ACTBWD) {
                     const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
                     esc[e] = c2.x; esh[e] = c2.y;
-                    vload<NT>(A.ex + mrow * (size_t)P + pc, xv[e]);
                 }
+                if (EPI_HAS_X(EPI)) vload<NT>(A.ex + mrow * (size_t)P + pc, xv[e]);
+                if (EPI == EPI_RESBWD) vload<NT>(A.emask + mrow * (size_t)P + pc, mk[e]);
                 if (has_add) {
                     const float* pa = A.addend + mrow * (size_t)addP;
                     if (NT == 4 && !add_s2) {
@@ -271,11 +277,12 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs A) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) v[j] += av[j] ? adv[e][j] : 0.f;
                 }
-                if (EPI == EPI_ACTBWD) {
+                if (EPI_HAS_X(EPI)) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const float xj = pv ? xv[e][j] : 0.f;
-                        v[j] = pv ? v[j] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                        if (EPI == EPI_RESBWD) v[j] = (pv && mk[e][j] > 0.f) ? v[j] : 0.f;
+                        else v[j] = pv ? v[j] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
                         s1 += v[j];
                         s2 = fmaf(v[j], xj, s2);
                     }
@@ -412,26 +419,54 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
     }
 
     // ------------------------------ epilogue ------------------------------
+    // Per 16-row tile: phase 1 issues the four rows' global reads (activation-derivative input,
+    // its coefficients, the residual addend) from clamped addresses, phase 2 combines and stores
+    // -- no load sits under a per-lane branch (see pw2_kernel).
+    const bool has_add = EPI != EPI_STATS && A.addend != nullptr;
+    const bool add_s2 = has_add && A.addend_stride == 2;
     int aoff[NT];
-    if (EPI != EPI_STATS && A.addend != nullptr) {
+    bool av[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int p = p0 + j;
-            if (A.addend_stride == 2) {
-                const int hw = A.H * A.W;
-                const int t = p / hw, rem = p - t * hw;
-                const int h = rem / A.W, w = rem - h * A.W;
-                aoff[j] = (pv && !(h & 1) && !(w & 1)) ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : -1;
-            } else {
-                aoff[j] = pv ? p : -1;
-            }
+    for (int j = 0; j < NT; ++j) {
+        const int p = min(p0 + j, P - 1);
+        av[j] = has_add && pv;
+        aoff[j] = p;
+        if (add_s2) {
+            const int hw = A.H * A.W;
+            const int t = p / hw, rem = p - t * hw;
+            const int h = rem / A.W, w = rem - h * A.W;
+            const bool even = !(h & 1) && !(w & 1);
+            av[j] = av[j] && even;
+            aoff[j] = even ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0;
         }
     }
-    const long long addP = (A.addend_stride == 2) ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+    const int pc = pv ? p0 : 0;                   // clamped voxel (NT-aligned)
 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (mt < mt_run) {
+            float xv[4][NT], mk[4][NT], adv[4][NT], esc[4], esh[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = mt * 16 + 4 * q + e;
+                const size_t mrow = (size_t)n * A.M + m0 + (ml < bm ? ml : 0);
+                if (EPI == EPI_ACTBWD) {
+                    const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
+                    esc[e] = c2.x; esh[e] = c2.y;
+                }
+                if (EPI_HAS_X(EPI)) vload<NT>(A.ex + mrow * (size_t)P + pc, xv[e]);
+                if (EPI == EPI_RESBWD) vload<NT>(A.emask + mrow * (size_t)P + pc, mk[e]);
+                if (has_add) {
+                    const float* pa = A.addend + mrow * (size_t)addP;
+                    if (NT == 4 && !add_s2) {
+                        vload<NT>(pa + pc, adv[e]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) adv[e][j] = pa[aoff[j]];
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = mt * 16 + 4 * q + e;
@@ -441,42 +476,30 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) v[j] = acc[mt][j][e];
                 float s1 = 0.f, s2 = 0.f;
-                if (mv && pv) {
-                    float* py = A.y + ((size_t)n * A.M + m) * (size_t)P + p0;
-                    if (EPI != EPI_STATS && A.addend != nullptr) {
-                        const float* pa = A.addend + ((size_t)n * A.M + m) * (size_t)addP;
-                        if (A.addend_stride == 1 && NT == 4) {
-                            float t4[NT];
-                            vload<NT>(pa + p0, t4);
+                if (has_add) {
 #pragma unroll
-                            for (int j = 0; j < NT; ++j) v[j] += t4[j];
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < NT; ++j) if (aoff[j] >= 0) v[j] += pa[aoff[j]];
-                        }
-                    }
-                    if (EPI == EPI_ACTBWD) {
-                        const float sc = A.ecoef[((size_t)n * A.M + m) * 2], sh = A.ecoef[((size_t)n * A.M + m) * 2 + 1];
-                        float xv[NT];
-                        vload<NT>(A.ex + ((size_t)n * A.M + m) * (size_t)P + p0, xv);
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            v[j] = v[j] * act_bwd(fmaf(sc, xv[j], sh), A.e_act);
-                            s1 += v[j];
-                            s2 = fmaf(v[j], xv[j], s2);
-                        }
-                    } else if (EPI == EPI_STATS) {
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
-                    }
-                    vstore<NT>(py, v);
+                    for (int j = 0; j < NT; ++j) v[j] += av[j] ? adv[e][j] : 0.f;
                 }
+                if (EPI_HAS_X(EPI)) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const float xj = pv ? xv[e][j] : 0.f;
+                        if (EPI == EPI_RESBWD) v[j] = (pv && mk[e][j] > 0.f) ? v[j] : 0.f;
+                        else v[j] = pv ? v[j] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                        s1 += v[j];
+                        s2 = fmaf(v[j], xj, s2);
+                    }
+                } else if (EPI == EPI_STATS) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) { v[j] = pv ? v[j] : 0.f; s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+                }
+                if (mv && pv) vstore<NT>(A.y + ((size_t)n * A.M + m) * (size_t)P + p0, v);
                 if (EPI != EPI_PLAIN) {
                     s1 = row16_sum(s1);
                     s2 = row16_sum(s2);
                     if (r == 0) {
-                        red[(wave * MT * 16 + ml) * 2] = s1;
-                        red[(wave * MT * 16 + ml) * 2 + 1] = s2;
+                        red[(wave * MT * 16 + ml) * 2] = mv ? s1 : 0.f;
+                        red[(wave * MT * 16 + ml) * 2 + 1] = mv ? s2 : 0.f;
                     }
                 }
             }
@@ -791,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
     }
     const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
     constexpr int NI = TWO ? 2 : 1;
-    float xv[NI][4][4], adv[NI][4][4], esc[NI][4], esh[NI][4];
+    float xv[NI][4][4], mk[NI][4][4], adv[NI][4][4], esc[NI][4], esh[NI][4];
     bool mvv[NI][4];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -804,6 +827,8 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
             if (EPI == EPI_ACTBWD) {
                 const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
                 esc[i][e] = c2.x; esh[i][e] = c2.y;
+            }
+            if (EPI_HAS_X(EPI)) {
                 const float* px = A.ex + mrow * (size_t)P;
                 if (VEC) {
                     const float4 t4 = *reinterpret_cast<const float4*>(px + (pv[0] ? pl : 0));
@@ -811,6 +836,16 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xv[i][e][j] = px[min(pl + j, P - 1)];
+                }
+            }
+            if (EPI == EPI_RESBWD) {
+                const float* pm = A.emask + mrow * (size_t)P;
+                if (VEC) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(pm + (pv[0] ? pl : 0));
+                    mk[i][e][0] = t4.x; mk[i][e][1] = t4.y; mk[i][e][2] = t4.z; mk[i][e][3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mk[i][e][j] = pm[min(pl + j, P - 1)];
                 }
             }
             if (has_add) {
@@ -840,11 +875,12 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const PwArgs A) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += av[j] ? adv[i][e][j] : 0.f;
             }
-            if (EPI == EPI_ACTBWD) {
+            if (EPI_HAS_X(EPI)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float xj = pv[j] ? xv[i][e][j] : 0.f;
-                    v[j] = pv[j] ? v[j] * act_bwd(fmaf(esc[i][e], xj, esh[i][e]), A.e_act) : 0.f;
+                    if (EPI == EPI_RESBWD) v[j] = (pv[j] && mk[i][e][j] > 0.f) ? v[j] : 0.f;
+                    else v[j] = pv[j] ? v[j] * act_bwd(fmaf(esc[i][e], xj, esh[i][e]), A.e_act) : 0.f;
                     s1 += v[j];
                     s2 = fmaf(v[j], xj, s2);
                 }
@@ -1050,7 +1086,7 @@ __global__ __launch_bounds__(256, 2) void pw4_kernel(const PwArgs A) {
         for (int j = 0; j < U; ++j) {
             const int lt = mpar + 2 * j;
             // phase 1: the four rows' reads, branch-free from clamped addresses
-            float xv[4][2], adv[4][2], esc[4], esh[4];
+            float xv[4][2], mk[4][2], adv[4][2], esc[4], esh[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = lt * 16 + 4 * q + e;
@@ -1058,8 +1094,14 @@ __global__ __launch_bounds__(256, 2) void pw4_kernel(const PwArgs A) {
                 if (EPI == EPI_ACTBWD) {
                     const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
                     esc[e] = c2.x; esh[e] = c2.y;
+                }
+                if (EPI_HAS_X(EPI)) {
                     const float2 t2 = *reinterpret_cast<const float2*>(A.ex + mrow * (size_t)P + pc);
                     xv[e][0] = t2.x; xv[e][1] = t2.y;
+                }
+                if (EPI == EPI_RESBWD) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(A.emask + mrow * (size_t)P + pc);
+                    mk[e][0] = t2.x; mk[e][1] = t2.y;
                 }
                 if (has_add) {
                     const float* pa = A.addend + mrow * (size_t)addP;
@@ -1079,11 +1121,12 @@ __global__ __launch_bounds__(256, 2) void pw4_kernel(const PwArgs A) {
                 float v[2] = {acc[j][0][e], acc[j][1][e]};
                 float s1 = 0.f, s2 = 0.f;
                 if (has_add) { v[0] += av[0] ? adv[e][0] : 0.f; v[1] += av[1] ? adv[e][1] : 0.f; }
-                if (EPI == EPI_ACTBWD) {
+                if (EPI_HAS_X(EPI)) {
 #pragma unroll
                     for (int j2 = 0; j2 < 2; ++j2) {
                         const float xj = pv ? xv[e][j2] : 0.f;
-                        v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                        if (EPI == EPI_RESBWD) v[j2] = (pv && mk[e][j2] > 0.f) ? v[j2] : 0.f;
+                        else v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
                         s1 += v[j2];
                         s2 = fmaf(v[j2], xj, s2);
                     }
@@ -1324,7 +1367,7 @@ __global__ __launch_bounds__(256, 2) void pw5_kernel(const PwArgs A) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int lt = mpar + 2 * j;
-            float xv[4][2], adv[4][2], esc[4], esh[4];
+            float xv[4][2], mk[4][2], adv[4][2], esc[4], esh[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = lt * 16 + 4 * q + e;
@@ -1332,8 +1375,14 @@ __global__ __launch_bounds__(256, 2) void pw5_kernel(const PwArgs A) {
                 if (EPI == EPI_ACTBWD) {
                     const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
                     esc[e] = c2.x; esh[e] = c2.y;
+                }
+                if (EPI_HAS_X(EPI)) {
                     const float2 t2 = *reinterpret_cast<const float2*>(A.ex + mrow * (size_t)P + pc);
                     xv[e][0] = t2.x; xv[e][1] = t2.y;
+                }
+                if (EPI == EPI_RESBWD) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(A.emask + mrow * (size_t)P + pc);
+                    mk[e][0] = t2.x; mk[e][1] = t2.y;
                 }
                 if (has_add) {
                     const float* pa = A.addend + mrow * (size_t)addP;
@@ -1352,11 +1401,12 @@ __global__ __launch_bounds__(256, 2) void pw5_kernel(const PwArgs A) {
                 float v[2] = {acc[j][0][e], acc[j][1][e]};
                 float s1 = 0.f, s2 = 0.f;
                 if (has_add) { v[0] += av[0] ? adv[e][0] : 0.f; v[1] += av[1] ? adv[e][1] : 0.f; }
-                if (EPI == EPI_ACTBWD) {
+                if (EPI_HAS_X(EPI)) {
 #pragma unroll
                     for (int j2 = 0; j2 < 2; ++j2) {
                         const float xj = pv ? xv[e][j2] : 0.f;
-                        v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                        if (EPI == EPI_RESBWD) v[j2] = (pv && mk[e][j2] > 0.f) ? v[j2] : 0.f;
+                        else v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
                         s1 += v[j2];
                         s2 = fmaf(v[j2], xj, s2);
                     }
@@ -2174,6 +2224,23 @@ extern "C" int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, 
     hipStream_t s = (hipStream_t)stream;
     if (pre) return launch_pw<IN_BNBWD, EPI_ACTBWD>(A, s);
     return launch_pw<IN_BNBWD, EPI_PLAIN>(A, s);
+}
+
+extern "C" int x3d_pw_bwd_data_res(const float* g, const float* a, const float* cb, const float* w,
+                                   const float* wpacked_t, float* out, int N, int Cin, int Cout, int T, int H, int W,
+                                   const float* res_out, const float* res_raw, const float* addend, int addend_stride,
+                                   float* partial, void* stream) {
+    X3D_CHECK_ARG(g && a && cb && w && out && res_out && res_raw && partial);
+    X3D_CHECK_ARG(N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && T > 0 && H > 0 && W > 0);
+    X3D_CHECK_ARG(addend_stride == 1 || addend_stride == 2);
+    PwArgs A = {};
+    A.x = g; A.a = a; A.cin = cb; A.w = w; A.wp = wpacked_t; A.w_ldk = Cin; A.w_ldm = 1; A.y = out;
+    A.N = N; A.K = Cout; A.M = Cin; A.P = T * H * W; A.Pin = A.P;
+    A.strided = 0; A.T = T; A.H = H; A.W = W;
+    A.Ho = (H - 1) / 2 + 1; A.Wo = (W - 1) / 2 + 1;
+    A.partial = partial; A.ex = res_raw; A.emask = res_out; A.ecoef = nullptr; A.e_act = X3D_ACT_RELU;
+    A.addend = addend; A.addend_stride = addend_stride;
+    return launch_pw<IN_BNBWD, EPI_RESBWD>(A, (hipStream_t)stream);
 }
 
 extern "C" int x3d_pw_wgrad_groups(int N, int P, int Cout, int Cin, int strideHW) {

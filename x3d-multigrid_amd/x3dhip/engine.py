@@ -123,6 +123,7 @@ class TrunkContext:
 
 
 _NO_DW_STATS = os.environ.get("X3D_NO_DW_STATS", "0") == "1"
+_NO_RES_FUSE = os.environ.get("X3D_NO_RES_FUSE", "0") == "1"
 
 
 def _bn_train(partial, bn, S, count, want_nsum=False):
@@ -282,19 +283,24 @@ def trunk_backward(model, ctx, dpooled, grads, part="all", state=None):
         _bn_bwd(grads, pp, S, P5, model.bn5, hd["save5"], out_cb=True)
         cb5 = grads.last_cb
         _wgrad(grads, model.conv5.weight, g5, a5, cb5, hd["x4"])
-        dcur, _ = ops.pw_bwd_data(g5, a5, cb5, _w2d(model.conv5.weight), wpt=hd["w5t"])
+        if _res_fusable(blocks[0]):
+            dcur = ops.pw_bwd_data_res(g5, a5, cb5, _w2d(model.conv5.weight), blocks[0]["out"], blocks[0]["a3"],
+                                       wpt=hd["w5t"])
+        else:
+            dcur, _ = ops.pw_bwd_data(g5, a5, cb5, _w2d(model.conv5.weight), wpt=hd["w5t"])
         del g5
         pstem = None
-        for rec in (blocks if part == "all" else blocks[:n_late]):
-            dcur, pstem = _block_backward(rec, dcur, grads)
+        last = len(blocks) if part == "all" else n_late
+        for i in range(last):
+            dcur, pstem = _block_backward(blocks[i], dcur, grads, blocks[i + 1] if i + 1 < len(blocks) else None)
         if part == "late":
             if grads.side is not None:
                 torch.cuda.current_stream().wait_stream(grads.side)
             return dcur, pstem
     else:
         dcur, pstem = state
-        for rec in blocks[n_late:]:
-            dcur, pstem = _block_backward(rec, dcur, grads)
+        for i in range(n_late, len(blocks)):
+            dcur, pstem = _block_backward(blocks[i], dcur, grads, blocks[i + 1] if i + 1 < len(blocks) else None)
 
     S = ctx.head["S"]
     st = ctx.stem
@@ -365,14 +371,26 @@ def _on_side(grads, fn, tensors):
     return r
 
 
-def _block_backward(rec, dout, grads):
+def _res_fusable(rec):
+    """The residual-add + ReLU backward of this block can ride in the epilogue of the data gradient that produces its
+    output gradient (no downsample branch: one statistics pair)."""
+    return rec is not None and rec["ad"] is None and not _NO_RES_FUSE
+
+
+def _block_backward(rec, dout, grads, below=None):
+    """dout: gradient of the block's output -- or, when the producer already applied this block's residual-add + ReLU
+    backward (_res_fusable), the pair (g3, p3).  `below` is the record of the block whose output is this block's input
+    (None for the first block)."""
     blk, S = rec["blk"], rec["S"]
     a1, a2, a3, ad = rec["a1"], rec["a2"], rec["a3"], rec["ad"]
     x_raw, x_coef = rec["x_raw"], rec["x_coef"]
     pre_act = ACT_RELU if x_coef is not None else ACT_NONE
     P1, P2 = a1[0, 0].numel(), a2[0, 0].numel()
 
-    g3, p3, pd = ops.bn_add_relu_bwd(dout, rec["out"], a3, ad)
+    if isinstance(dout, tuple):
+        (g3, p3), pd = dout, None
+    else:
+        g3, p3, pd = ops.bn_add_relu_bwd(dout, rec["out"], a3, ad)
     cb3 = _bn_bwd(grads, p3, S, P2, blk.bn3, rec["s3"])
 
     # conv3: weight gradient, then data gradient fused with the swish backward
@@ -416,6 +434,9 @@ def _block_backward(rec, dout, grads):
         astride = blk.stride
     else:
         addend, astride = g3, 1
+    if _res_fusable(below):
+        return ops.pw_bwd_data_res(g1, a1, cb1, _w2d(blk.conv1.weight), below["out"], below["a3"], addend=addend,
+                                   addend_stride=astride, wpt=rec["w1t"]), None
     dprev, pprev = ops.pw_bwd_data(g1, a1, cb1, _w2d(blk.conv1.weight), x=x_raw if x_coef is not None else None,
                                    pre=x_coef, pre_act=pre_act, addend=addend, addend_stride=astride, wpt=rec["w1t"])
     return dprev, pprev

@@ -87,6 +87,22 @@ def pw_bwd_data(g, a, cb, w, x=None, pre=None, pre_act=ACT_NONE, addend=None, ad
     return o, (partial if pre is not None else None)
 
 
+def pw_bwd_data_res(g, a, cb, w, res_out, res_raw, addend=None, addend_stride=1, wpt=None):
+    """pw_bwd_data with the residual-add + ReLU backward of the block that produced this conv's input in its epilogue:
+    returns (g3, partial) of that block -- what bn_add_relu_bwd(dout, out, a3) returns for a block without downsample."""
+    _need_cuda(g, a, cb, w, res_out, res_raw, addend)
+    L = _lib.lib()
+    N, Cout, T, H, W = g.shape
+    Cin = w.shape[1]
+    if tuple(res_out.shape) != (N, Cin, T, H, W) or tuple(res_raw.shape) != (N, Cin, T, H, W):
+        raise ValueError("pw_bwd_data_res: res_out / res_raw must be [N, Cin, T, H, W]")
+    o = _f((N, Cin, T, H, W), g)
+    partial = _f((N, Cin, L.x3d_pw_tiles(N, Cout, Cin, T * H * W, 1), 2), g)
+    check(L.x3d_pw_bwd_data_res(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(wpt), ptr(o), N, Cin, Cout, T, H, W, ptr(res_out),
+                                ptr(res_raw), ptr(addend), addend_stride, ptr(partial), _lib.stream()))
+    return o, partial
+
+
 def reduce_partials(partial, n_out, out=None):
     L = _lib.lib()
     groups = partial.shape[0]

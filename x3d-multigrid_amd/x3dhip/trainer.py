@@ -215,9 +215,10 @@ class Trainer:
                 engine.trunk_backward(self.model, tctx, None, sink, part="early", state=state)
         torch.cuda.current_stream().wait_stream(s)
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        # thread-local capture: the process group's watchdog thread may touch the HIP runtime while we capture
+        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
             loss, logits, tctx, sink, state = self._fwd_bwd_late(sx, sy)
-        with torch.cuda.graph(gb, pool=ga.pool()):
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
             engine.trunk_backward(self.model, tctx, None, sink, part="early", state=state)
         self.model._pending_tracked = pending
         sd = self.model.state_dict()
@@ -258,7 +259,7 @@ class Trainer:
                 self._fwd_bwd(sx, sy)
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.world > 1 else "global"):
             loss, logits = self._fwd_bwd(sx, sy)
         # undo the warm-up's side effects on BN running stats / counters
         self.model._pending_tracked = pending
