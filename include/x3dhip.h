@@ -120,8 +120,23 @@ int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb,
                       float* wpartial, int N, int Cin, int Cout, int T, int H, int W,
                       int strideHW, void* stream);
 
+/* Several weight gradients in as few launches as there are tile variants among them (jobs: the arguments of
+ * x3d_pw_bwd_weight, one struct per conv).  Nothing in the backward pass consumes a weight gradient, so the host may
+ * postpone them all to the end of the pass; results are bitwise those of the single calls. */
+typedef struct X3DWgradJob {
+    const float* g; const float* a; const float* cb; const float* x; const float* pre; float* wpartial;
+    int pre_act, N, Cin, Cout, T, H, W, strideHW;
+} X3DWgradJob;
+size_t x3d_wgrad_job_bytes(void);
+int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void* stream);
+
 /* out[i] = sum_g partial[g][i], g < groups, i < n  (fixed order, fp64 accumulate) */
 int x3d_reduce_partials(const float* partial, float* out, int groups, int n, void* stream);
+
+/* The same reduction for `njobs` independent (partial, out, groups, n) jobs in one launch (host arrays of length njobs;
+ * the weight-gradient group sums of a whole backward pass).  Bitwise identical to njobs x3d_reduce_partials calls. */
+int x3d_reduce_partials_batch(const float* const* partials, float* const* outs, const int* groups, const int* ns,
+                              int njobs, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Channelwise 3x3x3 convolution (conv3x3x3 x3d.py:87-95, Bottleneck.conv2 :114,150):

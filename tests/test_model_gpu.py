@@ -146,6 +146,7 @@ def test_blocks_tight_vs_oracle(shape):
         assert parity.rel(out.cpu().numpy(), out_ref.detach().numpy()) < 2e-5, name
         sink = engine._GradSink(False)
         dprev, _ = engine._block_backward(ctx.blocks[0], dout.float().to(dev), sink)
+        sink.flush()            # the weight-gradient group sums are batched into one launch per backward part
         grads = sink.written
         assert parity.rel(dprev.cpu().numpy(), xr.grad.numpy()) < 1e-3, name
         for k, v in leaf.items():

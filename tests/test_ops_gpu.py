@@ -336,3 +336,48 @@ def test_elementwise_and_sgd():
         opt.step()
         ops.sgd_fused(wd, (gr * (it + 1)).to(dev), md, 0.1, first=(it == 0))
     assert _rel(wd, p.detach()) < 1e-6
+
+
+def test_reduce_partials_batch_is_bitwise_the_single_reductions():
+    """One launch for many (partial, out) jobs (more than one kernel-argument batch of 96) == per-job reductions."""
+    from x3dhip import ops
+    dev = _dev()
+    jobs, refs = [], []
+    for j in range(130):
+        groups, n = 1 + (j * 7) % 45, 1 + (j * 131) % 700
+        p = _g(groups, n, seed=100 + j).float().to(dev)
+        o = torch.full((n,), float("nan"), device=dev)
+        jobs.append((p, o))
+        refs.append(ops.reduce_partials(p, n))
+    ops.reduce_partials_batch(jobs)
+    for (p, o), r in zip(jobs, refs):
+        assert torch.equal(o, r)
+        assert _rel(o, p.double().sum(0)) < 1e-6
+
+
+def test_pw_bwd_weight_batch_is_bitwise_the_single_launches():
+    """Every PW case (all tile variants, strided gathers, the non-tiled fallback shapes) twice over -- more than one
+    24-job kernel-argument batch per variant -- postponed into DeferredGrads and flushed: bitwise the per-conv results."""
+    from x3dhip import ops
+    dev = _dev()
+    to = lambda t: None if t is None else t.float().contiguous().to(dev)
+    d = ops.DeferredGrads()
+    outs, refs = [], []
+    for rep in range(4):
+        for ci, case in enumerate(PW_CASES):
+            N, Ci, Co, T, H, W, s, act = case
+            if N > 3 and rep > 0:
+                continue
+            Ho, Wo = xo.out_hw(H, s), xo.out_hw(W, s)
+            sd = 1000 * rep + 10 * ci
+            x = to(_g(N, Ci, T, H, W, seed=sd + 1))
+            pre = to(torch.stack([1 + 0.2 * _g(N, Ci, seed=sd + 3), 0.3 * _g(N, Ci, seed=sd + 4)], -1)) if act else None
+            g, a = to(_g(N, Co, T, Ho, Wo, seed=sd + 5)), to(_g(N, Co, T, Ho, Wo, seed=sd + 6))
+            cb = to(torch.stack([1 + 0.1 * _g(N, Co, seed=sd + 7), 0.1 * _g(N, Co, seed=sd + 8), 0.05 * _g(N, Co, seed=sd + 9)], -1))
+            refs.append(ops.pw_bwd_weight(g, a, cb, x, (Co, Ci), stride=s, pre=pre, pre_act=act))
+            outs.append(ops.pw_bwd_weight(g, a, cb, x, (Co, Ci), stride=s, pre=pre, pre_act=act, defer=d))
+    assert len(d.wjobs) == len(outs) > 48
+    d.flush()
+    assert not d.wjobs and not d.reduces
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)

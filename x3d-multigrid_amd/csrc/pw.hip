@@ -1934,7 +1934,7 @@ __device__ __forceinline__ void split_bf16x4(const float (&v)[4], bf16x4& hi, bf
 // GATHER: the input of a stride-(1,2,2) convolution (the downsample branch): its four voxels per slot are read at
 // (t, 2 ho, 2 wo) of the full-resolution input instead of as one float4.
 template <int CO, int CI, bool GATHER>
-__global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
+__device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, const int blk) {
     constexpr int ND = CO / 16, NX = CI / 16;            // staged float4 slots per thread (dY, input)
     constexpr int MW = CO / 64, NW = CI / 16;            // 16x16 tiles per wave: MW (dY) x NW (input)
     __shared__ __attribute__((aligned(16))) __bf16 Dh[CO * W3_LD];
@@ -1944,7 +1944,6 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, r = lane & 15;
-    const int blk = blockIdx.y;
     const int co0 = (blk / A.cib) * CO, ci0 = (blk % A.cib) * CI;
     const int P = A.P;
     const int cps = (P + W2_PT - 1) / W2_PT;            // chunks per sample
@@ -2059,7 +2058,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
         }
     };
 
-    int c = blockIdx.x;
+    int c = grp;
     if (c < total) {
         fetch(c);
         store(c);
@@ -2074,7 +2073,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
     }
 
     // D[i = co][j = ci]: lane (q, r), reg e -> co = tile*16 + 4q + e, ci = tile*16 + r
-    float* out = A.wpartial + (size_t)blockIdx.x * A.Co * A.Ci;
+    float* out = A.wpartial + (size_t)grp * A.Co * A.Ci;
 #pragma unroll
     for (int i = 0; i < MW; ++i)
 #pragma unroll
@@ -2084,6 +2083,32 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
                 const int oc = co0 + (MW * wave + i) * 16 + 4 * q + e, ic = ci0 + j * 16 + r;
                 if (oc < A.Co && ic < A.Ci) out[(size_t)oc * A.Ci + ic] = acc[i][j][e];
             }
+}
+
+template <int CO, int CI, bool GATHER>
+__global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
+    wgrad3_body<CO, CI, GATHER>(A, blockIdx.x, blockIdx.y);
+}
+
+// Every weight gradient of a backward pass that uses the same tile variant in one launch (up to WB_MAX jobs, passed by
+// value): nothing downstream of a weight gradient runs before the optimizer, so the host postpones them; one launch
+// keeps all CUs busy across the short per-layer problems (512 workgroups x 3 voxel chunks at stage 3) instead of
+// paying a ramp and a tail per layer.  Workgroup -> (job, group, channel block): job-local ids keep the
+// group-major order of the single launch (groups % 8 == 0, so a group's channel blocks still share one XCD's L2).
+constexpr int WB_MAX = 24;
+struct WgBatch {
+    WgArgs job[WB_MAX];
+    int wg0[WB_MAX + 1];
+    int njobs;
+};
+
+template <int CO, int CI, bool GATHER>
+__global__ __launch_bounds__(256, 2) void pw_wgrad3_batch_kernel(const WgBatch B) {
+    int j = 0;
+    while (j + 1 < B.njobs && (int)blockIdx.x >= B.wg0[j + 1]) ++j;
+    const int local = (int)blockIdx.x - B.wg0[j];
+    const int groups = B.job[j].groups;
+    wgrad3_body<CO, CI, GATHER>(B.job[j], local % groups, local / groups);
 }
 
 static bool wgrad2_ok(int P, long long Pin, int Co, int Ci, bool strided) {
@@ -2151,7 +2176,64 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (wave == 0 && i < n) out[i] = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
+// All group reductions of a backward pass in one launch: up to RB_MAX jobs per launch, passed by value (kernel
+// arguments); a workgroup finds its job by a scan of the workgroup prefix table.  Same per-output summation order as
+// reduce_partials_kernel -> bitwise identical results.
+constexpr int RB_MAX = 96;
+struct ReduceBatch {
+    const float* partial[RB_MAX];
+    float* out[RB_MAX];
+    int groups[RB_MAX];
+    int n[RB_MAX];
+    int wg0[RB_MAX + 1];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void reduce_partials_batch_kernel(const ReduceBatch B) {
+    __shared__ double red[4][64];
+    int j = 0;
+    while (j + 1 < B.njobs && (int)blockIdx.x >= B.wg0[j + 1]) ++j;          // uniform: scalar loads
+    const float* __restrict__ partial = B.partial[j];
+    float* __restrict__ out = B.out[j];
+    const int groups = B.groups[j], n = B.n[j];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = ((int)blockIdx.x - B.wg0[j]) * 64 + lane;
+    double s = 0.0;
+    if (i < n) {
+        int g = wave;
+        for (; g + 12 < groups; g += 16) {
+            const float v0 = partial[(size_t)g * n + i], v1 = partial[(size_t)(g + 4) * n + i];
+            const float v2 = partial[(size_t)(g + 8) * n + i], v3 = partial[(size_t)(g + 12) * n + i];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; g < groups; g += 4) s += (double)partial[(size_t)g * n + i];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && i < n) out[i] = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
 }  // namespace
+
+extern "C" int x3d_reduce_partials_batch(const float* const* partials, float* const* outs, const int* groups,
+                                         const int* ns, int njobs, void* stream) {
+    X3D_CHECK_ARG(partials && outs && groups && ns && njobs > 0);
+    for (int j0 = 0; j0 < njobs; j0 += RB_MAX) {
+        ReduceBatch B;
+        B.njobs = min(RB_MAX, njobs - j0);
+        int wg = 0;
+        for (int j = 0; j < B.njobs; ++j) {
+            X3D_CHECK_ARG(partials[j0 + j] && outs[j0 + j] && groups[j0 + j] > 0 && ns[j0 + j] > 0);
+            B.partial[j] = partials[j0 + j]; B.out[j] = outs[j0 + j]; B.groups[j] = groups[j0 + j]; B.n[j] = ns[j0 + j];
+            B.wg0[j] = wg;
+            wg += cdiv(ns[j0 + j], 64);
+        }
+        B.wg0[B.njobs] = wg;
+        hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, B);
+        X3D_LAUNCH_CHECK();
+    }
+    return X3D_OK;
+}
 
 extern "C" int x3d_pw_tiles(int N, int K, int M, int P, int dense) {
     int variant, tiles, mb, mt;
@@ -2302,6 +2384,75 @@ extern "C" int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb
     else WG_LAUNCH(4, 4);
 #undef WG_LAUNCH
     X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+struct X3DWgradJobC {          // mirrors X3DWgradJob (include/x3dhip.h)
+    const float* g; const float* a; const float* cb; const float* x; const float* pre; float* wpartial;
+    int pre_act, N, Cin, Cout, T, H, W, strideHW;
+};
+
+extern "C" size_t x3d_wgrad_job_bytes(void) { return sizeof(X3DWgradJobC); }
+
+extern "C" int x3d_pw_bwd_weight_batch(const void* jobs_, int njobs, void* stream) {
+    X3D_CHECK_ARG(jobs_ && njobs > 0);
+    const X3DWgradJobC* jobs = (const X3DWgradJobC*)jobs_;
+    hipStream_t s = (hipStream_t)stream;
+    const bool f32 = getenv("X3D_WGRAD_F32") != nullptr;
+    // variant id: bit 0 = CI 64, bit 1 = CO 128, bit 2 = gathered (strided) input; -1 = not a wgrad3 shape
+    static thread_local WgBatch B[8];
+    for (int v = 0; v < 8; ++v) { B[v].njobs = 0; B[v].wg0[0] = 0; }
+    auto launch = [&](int v) -> int {
+        WgBatch& b = B[v];
+        if (b.njobs == 0) return X3D_OK;
+        const dim3 grid(b.wg0[b.njobs]), block(256);
+        switch (v) {
+            case 0: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 32, false>), grid, block, 0, s, b); break;
+            case 1: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 64, false>), grid, block, 0, s, b); break;
+            case 2: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 32, false>), grid, block, 0, s, b); break;
+            case 3: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 64, false>), grid, block, 0, s, b); break;
+            case 4: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 32, true>), grid, block, 0, s, b); break;
+            case 5: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 64, true>), grid, block, 0, s, b); break;
+            case 6: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 32, true>), grid, block, 0, s, b); break;
+            default: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 64, true>), grid, block, 0, s, b); break;
+        }
+        b.njobs = 0;
+        X3D_LAUNCH_CHECK();
+        return X3D_OK;
+    };
+    for (int i = 0; i < njobs; ++i) {
+        const X3DWgradJobC& J = jobs[i];
+        X3D_CHECK_ARG(J.g && J.a && J.cb && J.x && J.wpartial);
+        X3D_CHECK_ARG(J.N > 0 && J.Cin > 0 && J.Cout > 0 && J.T > 0 && J.H > 0 && J.W > 0);
+        X3D_CHECK_ARG(J.strideHW == 1 || J.strideHW == 2);
+        WgArgs A = {};
+        const int Ho = J.strideHW == 2 ? (J.H - 1) / 2 + 1 : J.H, Wo = J.strideHW == 2 ? (J.W - 1) / 2 + 1 : J.W;
+        A.g = J.g; A.a = J.a; A.cb = J.cb; A.x = J.x; A.pre = J.pre; A.pre_act = J.pre_act; A.wpartial = J.wpartial;
+        A.N = J.N; A.Ci = J.Cin; A.Co = J.Cout; A.P = J.T * Ho * Wo; A.Pin = (long long)J.T * J.H * J.W;
+        A.strided = J.strideHW == 2; A.T = J.T; A.H = J.H; A.W = J.W; A.Ho = Ho; A.Wo = Wo;
+        A.units_per_sample = cdiv(A.P, WG_UNIT);
+        int tiled;
+        wgrad_plan(J.N, A.P, J.Cout, J.Cin, J.strideHW == 1 && (A.Pin % 4 == 0), &tiled, &A.groups, &A.cob, &A.cib,
+                   &A.ct_run, &A.it_run);
+        if (!tiled || f32) {           // shapes outside the split-bf16 tiled kernel: one launch of their own
+            const int rc = x3d_pw_bwd_weight(J.g, J.a, J.cb, J.x, J.pre, J.pre_act, J.wpartial, J.N, J.Cin, J.Cout, J.T,
+                                             J.H, J.W, J.strideHW, stream);
+            if (rc != X3D_OK) return rc;
+            continue;
+        }
+        const int v = (wg3_ci(J.Cin) == 64 ? 1 : 0) | (wg3_co(J.Cout) == 128 ? 2 : 0) | (A.strided ? 4 : 0);
+        WgBatch& b = B[v];
+        b.job[b.njobs] = A;
+        b.wg0[b.njobs + 1] = b.wg0[b.njobs] + A.groups * A.cob * A.cib;
+        if (++b.njobs == WB_MAX) {
+            const int rc = launch(v);
+            if (rc != X3D_OK) return rc;
+        }
+    }
+    for (int v = 0; v < 8; ++v) {
+        const int rc = launch(v);
+        if (rc != X3D_OK) return rc;
+    }
     return X3D_OK;
 }
 

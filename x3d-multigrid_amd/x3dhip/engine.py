@@ -124,6 +124,7 @@ class TrunkContext:
 
 _NO_DW_STATS = os.environ.get("X3D_NO_DW_STATS", "0") == "1"
 _NO_RES_FUSE = os.environ.get("X3D_NO_RES_FUSE", "0") == "1"
+_NO_BATCH_REDUCE = os.environ.get("X3D_NO_BATCH_REDUCE", "0") == "1"
 
 
 def _bn_train(partial, bn, S, count, want_nsum=False):
@@ -254,6 +255,12 @@ class _GradSink:
         self.direct = direct
         self.written = {}
         self.side = side          # HIP stream for the weight-gradient kernels (off the critical path)
+        # group sums of the weight-gradient partials, postponed to one launch per backward part (single-stream mode)
+        self.deferred = ops.DeferredGrads() if (side is None and not _NO_BATCH_REDUCE) else None
+
+    def flush(self):
+        if self.deferred is not None:
+            self.deferred.flush()
 
     def out(self, p):
         if self.direct and p.grad is not None:
@@ -294,6 +301,7 @@ def trunk_backward(model, ctx, dpooled, grads, part="all", state=None):
         for i in range(last):
             dcur, pstem = _block_backward(blocks[i], dcur, grads, blocks[i + 1] if i + 1 < len(blocks) else None)
         if part == "late":
+            grads.flush()
             if grads.side is not None:
                 torch.cuda.current_stream().wait_stream(grads.side)
             return dcur, pstem
@@ -312,6 +320,7 @@ def trunk_backward(model, ctx, dpooled, grads, part="all", state=None):
     dx_s, dwt = ops.dw5t_bwd(dcur, a_t, cb0, w_t.data, st["a_s"], dw_out=grads.out(w_t))
     grads.put(w_t, dwt)
     grads.put(w_s, ops.stem133_bwd_weight(st["x"], dx_s, w_s.shape, out=grads.out(w_s)))
+    grads.flush()
     if grads.side is not None:
         torch.cuda.current_stream().wait_stream(grads.side)
     return None
@@ -329,6 +338,14 @@ def _bn_bwd(grads, partial, S, count, bn, save, out_cb=True):
 _side_streams = {}
 
 
+def use_side_stream():
+    """Weight-gradient kernels on a second HIP stream: OFF by default.  It paid while the data-gradient chain was slow;
+    since the persistent dgrad / split-bf16 wgrad kernels the forked graph replays 3.8 % slower than the linear one
+    (10.85 vs 10.46 ms at config 2: the overlapped kernels slow each other down by about what the overlap hides, and
+    every fork / join is a cross-queue dependency).  X3D_SIDE_STREAM=1 turns it back on."""
+    return os.environ.get("X3D_SIDE_STREAM") == "1" and os.environ.get("X3D_NO_SIDE_STREAM") != "1"
+
+
 def side_stream(device):
     """One extra HIP stream per device for work that is off the backward critical path."""
     st = _side_streams.get(device)
@@ -342,9 +359,13 @@ def _wgrad(grads, w, g, a, cb, x, **kw):
     """Pointwise weight gradient.  Nothing downstream in the backward pass consumes it, so it runs
     on the side stream, concurrently with the data-gradient chain (the small stage-3/4 kernels
     cannot fill 256 CUs on their own); joined once at the end of trunk_backward."""
+    if os.environ.get("X3D_EXP_SKIP_WGRAD") == "1":      # timing experiment only: gradients are wrong
+        o = grads.out(w)
+        grads.put(w, o if o is not None else torch.zeros_like(w))
+        return
     side = grads.side
     if side is None:
-        grads.put(w, ops.pw_bwd_weight(g, a, cb, x, w.shape, out=grads.out(w), **kw))
+        grads.put(w, ops.pw_bwd_weight(g, a, cb, x, w.shape, out=grads.out(w), defer=grads.deferred, **kw))
         return
     main = torch.cuda.current_stream()
     side.wait_stream(main)
@@ -421,7 +442,8 @@ def _block_backward(rec, dout, grads, below=None):
     del ds
     # the group sum of the 27-tap partials feeds only the optimizer: side stream
     w2 = blk.conv2.weight
-    grads.put(w2, _on_side(grads, lambda: ops.dw333_bwd_reduce(wpart2, w2.shape, grads.out(w2)), (wpart2,)))
+    grads.put(w2, _on_side(grads, lambda: ops.dw333_bwd_reduce(wpart2, w2.shape, grads.out(w2), defer=grads.deferred),
+                           (wpart2,)))
     cb1 = _bn_bwd(grads, p1, S, P1, blk.bn1, rec["s1"])
 
     # conv1 (+ downsample branch)
@@ -468,7 +490,7 @@ class TrunkFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpooled):
         import os
-        side = None if os.environ.get("X3D_NO_SIDE_STREAM") == "1" else side_stream(dpooled.device)
+        side = side_stream(dpooled.device) if use_side_stream() else None
         sink = _GradSink(getattr(ctx.model, "_direct_grads", False), side)
         trunk_backward(ctx.model, ctx.tctx, dpooled, sink)
         ctx.tctx = None

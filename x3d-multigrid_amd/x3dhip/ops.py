@@ -4,6 +4,8 @@ PyTorch is used for device memory and streams only: every function below allocat
 with torch, passes raw pointers to libx3dhip.so on the current HIP stream and returns
 tensors.  There is no fallback: a missing library or a CPU tensor raises.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -111,7 +113,52 @@ def reduce_partials(partial, n_out, out=None):
     return o
 
 
-def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, out=None, wpartial=None):
+def reduce_partials_batch(jobs):
+    """jobs: list of (partial [groups, n] contiguous, out [n]) -- every out[i] = sum_g partial[g][i] in ONE launch (per
+    96 jobs).  The tensors must stay alive until the launch has been enqueued (they are: the caller holds the list)."""
+    if not jobs:
+        return
+    L = _lib.lib()
+    nj = len(jobs)
+    parts = (ctypes.c_void_p * nj)(*[p.data_ptr() for p, _ in jobs])
+    outs = (ctypes.c_void_p * nj)(*[o.data_ptr() for _, o in jobs])
+    groups = (ctypes.c_int * nj)(*[p.shape[0] for p, _ in jobs])
+    ns = (ctypes.c_int * nj)(*[p.shape[1] for p, _ in jobs])
+    for p, o in jobs:
+        if not (p.is_contiguous() and o.is_contiguous() and o.numel() == p.shape[1] and p.dtype == o.dtype == torch.float32):
+            raise ValueError("reduce_partials_batch: partial must be contiguous float32 [groups, n], out float32 [n]")
+    check(L.x3d_reduce_partials_batch(ctypes.cast(parts, ctypes.c_void_p), ctypes.cast(outs, ctypes.c_void_p),
+                                      ctypes.cast(groups, ctypes.c_void_p), ctypes.cast(ns, ctypes.c_void_p), nj,
+                                      _lib.stream()))
+
+
+class _WgradJob(ctypes.Structure):          # X3DWgradJob (include/x3dhip.h)
+    _fields_ = [("g", ctypes.c_void_p), ("a", ctypes.c_void_p), ("cb", ctypes.c_void_p), ("x", ctypes.c_void_p),
+                ("pre", ctypes.c_void_p), ("wpartial", ctypes.c_void_p), ("pre_act", ctypes.c_int), ("N", ctypes.c_int),
+                ("Cin", ctypes.c_int), ("Cout", ctypes.c_int), ("T", ctypes.c_int), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("strideHW", ctypes.c_int)]
+
+
+class DeferredGrads:
+    """Weight-gradient work of a backward pass, postponed to a few launches at its end (nothing downstream consumes a
+    weight gradient): `wjobs` -- pointwise weight-gradient kernels (x3d_pw_bwd_weight_batch), `reduces` -- the group sums
+    of their partials and of the channelwise convs' (x3d_reduce_partials_batch).  Holds every tensor it points to."""
+
+    def __init__(self):
+        self.wjobs, self.keep, self.reduces = [], [], []
+
+    def flush(self):
+        L = _lib.lib()
+        if self.wjobs:
+            if L.x3d_wgrad_job_bytes() != ctypes.sizeof(_WgradJob):
+                raise RuntimeError("X3DWgradJob layout mismatch between libx3dhip and x3dhip.ops")
+            arr = (_WgradJob * len(self.wjobs))(*self.wjobs)
+            check(L.x3d_pw_bwd_weight_batch(ctypes.cast(arr, ctypes.c_void_p), len(self.wjobs), _lib.stream()))
+        reduce_partials_batch(self.reduces)
+        self.wjobs, self.keep, self.reduces = [], [], []
+
+
+def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, out=None, wpartial=None, defer=None):
     _need_cuda(g, a, cb, x, pre)
     L = _lib.lib()
     N, Cin, T, H, W = x.shape
@@ -120,6 +167,16 @@ def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, ou
     groups = L.x3d_pw_wgrad_groups(N, T * Ho * Wo, Cout, Cin, stride)
     if wpartial is None:
         wpartial = _f((groups, Cout, Cin), g)
+    if defer is not None:                 # kernel and group sum postponed to the batched launches (DeferredGrads.flush)
+        for t in (g, a, cb, x) + ((pre,) if pre is not None else ()):
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                raise ValueError("pw_bwd_weight: contiguous float32 tensors required")
+        o = out if out is not None else _f((Cout * Cin,), g)
+        defer.wjobs.append(_WgradJob(ptr(g), ptr(a), ptr(cb), ptr(x), ptr(pre), ptr(wpartial), pre_act, N, Cin, Cout, T,
+                                     H, W, stride))
+        defer.keep.append((g, a, cb, x, pre, wpartial))
+        defer.reduces.append((wpartial.view(groups, -1), o))
+        return o.view(w_shape)
     check(L.x3d_pw_bwd_weight(ptr(g), ptr(a), ptr(cb), ptr(x), ptr(pre), pre_act, ptr(wpartial), N, Cin, Cout, T,
                               H, W, stride, _lib.stream()))
     dw = reduce_partials(wpartial.view(groups, -1), Cout * Cin, out=out)
@@ -177,9 +234,13 @@ def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wp
     return o, dw333_bwd_reduce(wpartial, w.shape, dw_out), partial
 
 
-def dw333_bwd_reduce(wpartial, w_shape, dw_out=None):
+def dw333_bwd_reduce(wpartial, w_shape, dw_out=None, defer=None):
     """dW[c][27] = sum over (n, tile) groups of the [N][tiles][C][27] partials."""
     N, tiles, C, _ = wpartial.shape
+    if defer is not None:
+        o = dw_out if dw_out is not None else _f((C * 27,), wpartial)
+        defer.reduces.append((wpartial.view(N * tiles, C * 27), o))
+        return o.view(w_shape)
     dw = reduce_partials(wpartial.view(N * tiles, C * 27), C * 27, out=dw_out)
     return dw.view(w_shape)
 

@@ -197,7 +197,7 @@ class Trainer:
         logits = model.fc2(model.dropout(h)).unsqueeze(2)
         loss = F.cross_entropy(logits, y)
         loss.backward(inputs=[pooled, model.fc1.weight, model.fc2.weight, model.fc2.bias])       # into the flat .grad views
-        side = None if os.environ.get("X3D_NO_SIDE_STREAM") == "1" else engine.side_stream(x.device)
+        side = engine.side_stream(x.device) if engine.use_side_stream() else None
         sink = engine._GradSink(True, side)
         state = engine.trunk_backward(model, tctx, pooled.grad, sink, part="late")
         return loss.detach(), logits.detach(), tctx, sink, state
