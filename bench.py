@@ -59,8 +59,28 @@ class KernelTimer:
         self.records = []
         self._orig = {}
 
+    # ops that are a fused form of another family's pass: reported under that family
+    ALIAS = {"pw_bwd_data_res": "pw_bwd_data", "dw333_fwd_stats": "dw333_fwd"}
+
     def __enter__(self):
-        for name in ("pw_fwd", "pw_bwd_data", "pw_bwd_weight", "dw333_fwd", "dw333_bwd", "stem133_fwd",
+        self.pending_wbytes, self.pending_wjobs = 0, 0
+        flush0 = self.ops.DeferredGrads.flush
+        timer = self
+
+        def flush(d):
+            # the postponed weight gradients: every conv's kernel + the group sums, a few launches for the whole pass
+            if not d.wjobs and not d.reduces:
+                return flush0(d)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            flush0(d)
+            e1.record()
+            timer.records.append(("pw_bwd_weight", e0, e1, timer.pending_wbytes, "batched x%d" % timer.pending_wjobs))
+            timer.pending_wbytes, timer.pending_wjobs = 0, 0
+
+        self._flush0 = flush0
+        self.ops.DeferredGrads.flush = flush
+        for name in ("pw_fwd", "pw_bwd_data", "pw_bwd_data_res", "pw_bwd_weight", "dw333_fwd", "dw333_fwd_stats", "dw333_bwd", "stem133_fwd",
                      "stem133_bwd_weight", "dw5t_fwd", "dw5t_bwd", "bn_add_relu_fwd", "bn_stats_add_relu_fwd", "bn_add_relu_bwd",
                      "bn_relu_pool_fwd", "bn_relu_pool_bwd", "bn_fwd_finalize", "bn_bwd_finalize", "se_fwd",
                      "se_bn_bwd_finalize", "sgd_fused"):
@@ -71,6 +91,10 @@ class KernelTimer:
 
     def _wrap(self, name, fn):
         def inner(*a, **k):
+            if name == "pw_bwd_weight" and k.get("defer") is not None:       # runs inside DeferredGrads.flush
+                self.pending_wbytes += _alg_bytes(name, a, k, None)
+                self.pending_wjobs += 1
+                return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = fn(*a, **k)
@@ -78,13 +102,14 @@ class KernelTimer:
             shp = "x".join(map(str, a[0].shape)) if hasattr(a[0], "shape") else ""
             if name.startswith("pw_"):
                 shp += " w=" + "x".join(map(str, (a[1] if name == "pw_fwd" else a[3]).shape[:2])) if name != "pw_bwd_weight" else " w=" + "x".join(map(str, a[4][:2]))
-            self.records.append((name, e0, e1, _alg_bytes(name, a, k, r), shp))
+            self.records.append((self.ALIAS.get(name, name), e0, e1, _alg_bytes(name, a, k, r), shp))
             return r
         return inner
 
     def __exit__(self, *exc):
         for name, fn in self._orig.items():
             setattr(self.ops, name, fn)
+        self.ops.DeferredGrads.flush = self._flush0
 
     def summary(self):
         torch.cuda.synchronize()
@@ -105,12 +130,12 @@ def _alg_bytes(name, a, k, r):
     elementwise pass it implements (what the pass must move at minimum)."""
     n = lambda t: t.numel()
     try:
-        if name in ("pw_fwd", "dw333_fwd", "dw5t_fwd", "stem133_fwd"):
+        if name in ("pw_fwd", "dw333_fwd", "dw333_fwd_stats", "dw5t_fwd", "stem133_fwd"):
             x, y = a[0], (r[0] if isinstance(r, tuple) else r)
             stride = k.get("stride", 1)
             xin = n(x) // (stride * stride) if name == "pw_fwd" else n(x)
             return 4 * (xin + n(y))
-        if name == "pw_bwd_data":
+        if name in ("pw_bwd_data", "pw_bwd_data_res"):
             return 4 * (n(a[0]) + n(r[0]))
         if name == "pw_bwd_weight":
             stride = k.get("stride", 1)
@@ -266,8 +291,15 @@ def main():
             tr_e.step(x, y)
             torch.cuda.synchronize()
     if rank == 0 and not args.no_kernel_timing:
+        # The eager step is host-bound (a ctypes launch costs more than most of these kernels run): with an empty queue
+        # an event pair would measure the host's time between the two records.  ~60 ms of unrelated GEMM work is queued
+        # first, so the whole instrumented step is enqueued behind it and the events see back-to-back device execution.
+        blocker = torch.empty(8192, 8192, device=x.device).normal_()
+        for _ in range(8):
+            blocker @ blocker
         with KernelTimer(ops) as kt:
             tr_e.step(x, y)
+        del blocker
         agg = kt.summary()
         if args.dump_launches:
             with open(args.dump_launches, "w") as f:
