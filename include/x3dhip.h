@@ -171,6 +171,14 @@ int x3d_dw333_bwd(const float* g, const float* a, const float* cb, const float* 
                   float* out, float* wpartial, float* partial,
                   int N, int C, int T, int H, int W, int strideHW, void* stream);
 
+/* The same with the producer BN's backward finalize folded in (single split, num_splits == 1): the coefficients are
+ * derived inside the kernel from spartial float[N][C][stiles][2] = {sum g, sum g*a} (the statistics the kernel that
+ * wrote g left), gamma and save = {mean[C], invstd[C]}; dgamma / dbeta float[C] are written (not accumulated). */
+int x3d_dw333_bwd_stats(const float* g, const float* a, const float* spartial, int stiles, int count,
+                        const float* gamma, const float* save, float* dgamma, float* dbeta, const float* w,
+                        const float* x, const float* pre, int pre_act, float* out, float* wpartial, float* partial,
+                        int N, int C, int T, int H, int W, int strideHW, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Stem (x3d.py:196-208,317-318): dense 1x3x3 s(1,2,2) 3->C, then depthwise temporal 5x1x1.
  * ---------------------------------------------------------------------------------- */

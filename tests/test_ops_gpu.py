@@ -381,3 +381,30 @@ def test_pw_bwd_weight_batch_is_bitwise_the_single_launches():
     assert not d.wjobs and not d.reduces
     for o, r in zip(outs, refs):
         assert torch.equal(o, r)
+
+
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dw333_bwd_stats_equals_finalize_then_conv(case):
+    """BN-backward finalize (single split) folded into the depthwise backward prologue == bn_bwd_finalize + dw333_bwd."""
+    from x3dhip import ops
+    dev = _dev()
+    N, C, T, H, W, s = case
+    Ho, Wo = xo.out_hw(H, s), xo.out_hw(W, s)
+    to = lambda t: t.float().contiguous().to(dev)
+    x = to(_g(N, C, T, H, W, seed=1))
+    w = to(_g(C, 1, 3, 3, 3, seed=2) / 3)
+    pre = to(torch.stack([1 + 0.2 * _g(N, C, seed=3), 0.3 * _g(N, C, seed=4)], -1))
+    g, a = to(_g(N, C, T, Ho, Wo, seed=5)), to(_g(N, C, T, Ho, Wo, seed=6))
+    gamma = to(1 + 0.2 * _g(C, seed=13))
+    save = to(torch.stack([0.1 * _g(1, C, seed=15), 1 + 0.1 * _g(1, C, seed=16).abs()], 0))      # [2, 1, C]
+    P = T * Ho * Wo
+    for stiles in (1, 5, 130):
+        sp = to(torch.stack([_g(N, C, stiles, seed=11), 2 * _g(N, C, stiles, seed=12)], -1))
+        cb, dg_ref, db_ref = ops.bn_bwd_finalize(sp, 1, P, gamma, save)
+        out_ref, dw_ref, bp_ref = ops.dw333_bwd(g, a, cb, w, x, stride=s, pre=pre, pre_act=1)
+        dg, db = torch.full_like(gamma, float("nan")), torch.full_like(gamma, float("nan"))
+        out, dw, bp = ops.dw333_bwd(g, a, None, w, x, stride=s, pre=pre, pre_act=1, bn=(sp, P, gamma, save, dg, db))
+        assert _rel(dg, dg_ref) < 1e-6 and _rel(db, db_ref) < 1e-6
+        assert _rel(out, out_ref) < 1e-5
+        assert _rel(dw, dw_ref) < 1e-5
+        assert _rel(bp.double().sum(2), bp_ref.double().sum(2)) < 1e-5

@@ -387,6 +387,10 @@ struct DwBwdArgs {
     const float* x; const float* pre; int pre_act;
     float* out; float* wpartial; float* partial;
     DwGeom geo;
+    // cb == NULL: the producer BN's backward finalize (one split) is folded into this kernel: A, B, C of the workgroup's
+    // channels are derived from the statistics partials sp[N][C][stiles][2] = {sum g, sum g*a} of the kernel that wrote g
+    const float* sp; int stiles, count;
+    const float* gamma; const float* save; float* dgamma; float* dbeta;
 };
 
 template <int NCH, bool VEC>
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         k0[i] = k1[i] = k2[i] = 0.f;
-        if (ch[i].goff >= 0) {
+        if (A.cb != nullptr && ch[i].goff >= 0) {
             const int cg = ch[i].goff / (g.T * g.Ho * g.Wo);
             const float* cb = A.cb + ((size_t)n * g.C + cg) * 3;
             k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
@@ -455,9 +459,61 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     const int plane_o = g.Ho * g.Wo;
 
     float4 rg[NCH], ra[NCH];
-    __syncthreads();
-    fetch4<NCH, VEC>(gb, ch, 0, true, rg);
+    fetch4<NCH, VEC>(gb, ch, 0, true, rg);               // addresses only: in flight during the statistics below
     fetch4<NCH, VEC>(ab, ch, 0, true, ra);
+    if (A.cb == nullptr) {
+        // BN backward finalize of this workgroup's channels (single split; x3d.py:47-58 backward): fp64 sums over all
+        // samples x stiles partial pairs in a fixed order (identical in every workgroup of a channel); the (tile 0,
+        // sample 0) workgroup writes dgamma / dbeta.
+        __shared__ double dred[16 * 4 * 2];
+        __shared__ float lcb[16 * 3];
+        const int lane = tid & 63, wave = tid >> 6;
+        const int ne = g.N * A.stiles;
+        const int wpc = g.cpb == 1 ? 4 : (g.cpb == 2 ? 2 : 1), cpp = 4 / wpc;    // waves per channel, channels per pass
+        for (int cb0 = 0; cb0 < g.cpb; cb0 += cpp) {
+            const int ccs = cb0 + wave / wpc, sub = wave % wpc;
+            if (ccs < g.cpb) {
+                const int cg = min(c0 + ccs, g.C - 1);
+                double s1 = 0.0, s2 = 0.0;
+                for (int e = sub * 64 + lane; e < ne; e += 64 * wpc) {
+                    const int k = e / A.stiles, t = e - k * A.stiles;
+                    const float2 v = *reinterpret_cast<const float2*>(A.sp + (((size_t)k * g.C + cg) * A.stiles + t) * 2);
+                    s1 += (double)v.x;
+                    s2 += (double)v.y;
+                }
+                for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                if (lane == 0) { dred[(ccs * 4 + sub) * 2] = s1; dred[(ccs * 4 + sub) * 2 + 1] = s2; }
+            }
+        }
+        __syncthreads();
+        if (tid < g.cpb) {
+            double sg = 0.0, sga = 0.0;
+            for (int u = 0; u < wpc; ++u) { sg += dred[(tid * 4 + u) * 2]; sga += dred[(tid * 4 + u) * 2 + 1]; }
+            const int cg = min(c0 + tid, g.C - 1);
+            const double M = (double)A.count * (double)g.N;
+            const double mean = A.save[cg], invstd = A.save[(size_t)g.C + cg];
+            const double sgx = (sga - mean * sg) * invstd;
+            const double k = (double)A.gamma[cg] * invstd;
+            lcb[tid * 3] = (float)k;
+            lcb[tid * 3 + 1] = (float)(-k * invstd * sgx / M);
+            lcb[tid * 3 + 2] = (float)(-k * sg / M + k * invstd * mean * sgx / M);
+            if (tile == 0 && n == 0 && c0 + tid < g.C) {
+                A.dgamma[cg] = (float)sgx;
+                A.dbeta[cg] = (float)sg;
+            }
+        }
+        __syncthreads();                                   // also orders the ring zero-fill before the staging below
+        const int chvol = g.T * g.Ho * g.Wo;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (ch[i].goff >= 0) {
+                const int ci = ch[i].goff / chvol - c0;
+                k0[i] = lcb[ci * 3]; k1[i] = lcb[ci * 3 + 1]; k2[i] = lcb[ci * 3 + 2];
+            }
+        }
+    } else {
+        __syncthreads();
+    }
     store_dy<NCH, VEC>(ring, ch, true, k0, k1, k2, rg, ra);
     fetch4<NCH, VEC>(gb, ch, plane_o, g.T > 1, rg);
     fetch4<NCH, VEC>(ab, ch, plane_o, g.T > 1, ra);
@@ -742,7 +798,29 @@ extern "C" int x3d_dw333_bwd(const float* g, const float* a, const float* cb, co
     DwBwdArgs A;
     A.g = g; A.a = a; A.cb = cb; A.w = w; A.x = x; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE;
     A.out = out; A.wpartial = wpartial; A.partial = partial;
+    A.sp = nullptr; A.stiles = 0; A.count = 0; A.gamma = A.save = nullptr; A.dgamma = A.dbeta = nullptr;
     A.geo = make_geom(N, C, T, H, W, strideHW, true);
+    const size_t ldsb = bwd_lds_bytes(A.geo);
+    if (ldsb > 160 * 1024) { x3d_set_error("dw333_bwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    DW_DISPATCH(dw_bwd_kernel, A, A.geo, ldsb);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_dw333_bwd_stats(const float* g, const float* a, const float* spartial, int stiles, int count,
+                                   const float* gamma, const float* save, float* dgamma, float* dbeta, const float* w,
+                                   const float* x, const float* pre, int pre_act, float* out, float* wpartial,
+                                   float* partial, int N, int C, int T, int H, int W, int strideHW, void* stream) {
+    X3D_CHECK_ARG(g && a && spartial && gamma && save && dgamma && dbeta && w && x && out && wpartial);
+    X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0 && stiles > 0 && count > 0);
+    X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
+    DwBwdArgs A;
+    A.g = g; A.a = a; A.cb = nullptr; A.w = w; A.x = x; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE;
+    A.out = out; A.wpartial = wpartial; A.partial = partial;
+    A.sp = spartial; A.stiles = stiles; A.count = count; A.gamma = gamma; A.save = save; A.dgamma = dgamma; A.dbeta = dbeta;
+    A.geo = make_geom(N, C, T, H, W, strideHW, true);
+    X3D_CHECK_ARG(A.geo.cpb <= 16);
     const size_t ldsb = bwd_lds_bytes(A.geo);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_bwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;

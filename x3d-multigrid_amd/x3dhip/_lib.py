@@ -47,6 +47,7 @@ SIGNATURES = {
     "x3d_dw_tiles": (_I, [_I, _I]),
     "x3d_dw333_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "x3d_dw_bwd_tiles": (_I, [_I, _I, _I]),
+    "x3d_dw333_bwd_stats": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_dw333_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_stem133_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_stem_wgrad_groups": (_I, [_I, _I]),

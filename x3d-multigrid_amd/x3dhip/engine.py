@@ -123,6 +123,7 @@ class TrunkContext:
 
 
 _NO_DW_STATS = os.environ.get("X3D_NO_DW_STATS", "0") == "1"
+_DW_BWD_STATS = os.environ.get("X3D_DW_BWD_STATS", "1") == "1"
 _NO_RES_FUSE = os.environ.get("X3D_NO_RES_FUSE", "0") == "1"
 _NO_BATCH_REDUCE = os.environ.get("X3D_NO_BATCH_REDUCE", "0") == "1"
 
@@ -433,12 +434,22 @@ def _block_backward(rec, dout, grads, below=None):
         grads.put(blk.fc1.bias, o["db1"])
         grads.put(blk.fc2.weight, o["dw2"])
         grads.put(blk.fc2.bias, o["db2"])
+    elif S == 1 and _DW_BWD_STATS:
+        cb2 = None          # bn2's backward finalize runs in the depthwise kernel's prologue
     else:
         cb2 = _bn_bwd(grads, ps, S, P2, blk.bn2, rec["s2"])
 
     # conv2 (channelwise): fused data + weight backward, relu backward of bn1 in its epilogue
+    bn2 = None
+    if cb2 is None:
+        dg2, db2 = grads.out(blk.bn2.weight), grads.out(blk.bn2.bias)
+        if dg2 is None:
+            dg2, db2 = torch.empty_like(blk.bn2.weight.data), torch.empty_like(blk.bn2.bias.data)
+        bn2 = (ps, P2, blk.bn2.weight.data, rec["s2"], dg2, db2)
+        grads.put(blk.bn2.weight, dg2)
+        grads.put(blk.bn2.bias, db2)
     g1, wpart2, p1 = ops.dw333_bwd(ds, a2, cb2, blk.conv2.weight.data, a1, stride=blk.stride, pre=rec["c1"],
-                                   pre_act=ACT_RELU, reduce=False)
+                                   pre_act=ACT_RELU, reduce=False, bn=bn2)
     del ds
     # the group sum of the 27-tap partials feeds only the optimizer: side stream
     w2 = blk.conv2.weight

@@ -215,9 +215,11 @@ def dw333_fwd_stats(x, w, spartial, S, count, gamma, beta, running_mean, running
 
 
 def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wpartial=None, partial=None,
-              dw_out=None, reduce=True):
+              dw_out=None, reduce=True, bn=None):
     """reduce=False: returns (out, wpartial, partial) and leaves the [N*tiles] -> 1 group sum of the weight-gradient
-    partials to dw333_bwd_reduce (the engine runs it on its side stream: nothing in the backward chain reads dW)."""
+    partials to dw333_bwd_reduce (postponed by the engine: nothing in the backward chain reads dW).
+    bn = (spartial [N,C,stiles,2], count, gamma, save [2,1,C], dgamma [C], dbeta [C]) with cb = None: the producer BN's
+    backward finalize (single split) runs in the kernel's prologue; dgamma / dbeta are written."""
     _need_cuda(g, a, cb, w, x, pre)
     L = _lib.lib()
     N, C, T, H, W = x.shape
@@ -227,8 +229,17 @@ def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wp
         wpartial = _f((N, tiles, C, 27), x)
     if partial is None:
         partial = _f((N, C, tiles, 2), x)
-    check(L.x3d_dw333_bwd(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(x), ptr(pre), pre_act, ptr(o), ptr(wpartial),
-                          ptr(partial), N, C, T, H, W, stride, _lib.stream()))
+    if bn is not None:
+        sp, count, gamma, save, dgamma, dbeta = bn
+        if cb is not None or save.numel() != 2 * C or tuple(sp.shape[:2]) != (N, C):
+            raise ValueError("dw333_bwd: bn=... needs cb=None, a single BN split and spartial [N, C, tiles, 2]")
+        _need_cuda(sp, gamma, save, dgamma, dbeta)
+        check(L.x3d_dw333_bwd_stats(ptr(g), ptr(a), ptr(sp), sp.shape[2], count, ptr(gamma), ptr(save), ptr(dgamma),
+                                    ptr(dbeta), ptr(w), ptr(x), ptr(pre), pre_act, ptr(o), ptr(wpartial), ptr(partial),
+                                    N, C, T, H, W, stride, _lib.stream()))
+    else:
+        check(L.x3d_dw333_bwd(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(x), ptr(pre), pre_act, ptr(o), ptr(wpartial),
+                              ptr(partial), N, C, T, H, W, stride, _lib.stream()))
     if not reduce:
         return o, wpartial, partial
     return o, dw333_bwd_reduce(wpartial, w.shape, dw_out), partial
