@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
 // SE forward: one workgroup per sample
 // ------------------------------------------------------------------------------------
 constexpr int SE_MAXC = 1024, SE_MAXW = 64;
+constexpr int SE_PB = 16;          // hidden units per block-reduction round of the SE kernels
 
 __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ coef, const float* __restrict__ nsum,
                                                      int C, int Wd, int count, const float* __restrict__ w1,
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ c
                                                      float* __restrict__ save_pool) {
     __shared__ float pool[SE_MAXC];
     __shared__ float z[SE_MAXW];
+    __shared__ float part[SE_PB][4];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c < C; c += 256) {
         const float sc = coef[((size_t)n * C + c) * 2], sh = coef[((size_t)n * C + c) * 2 + 1];
@@ -218,18 +220,32 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ c
         save_pool[(size_t)n * C + c] = p;
     }
     __syncthreads();
-    for (int w = wave; w < Wd; w += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s = fmaf(w1[(size_t)w * C + c], pool[c], s);
-        s = wave_sum(s);
-        if (lane == 0) {
-            s += b1[w];
-            s = s > 0.f ? s : 0.f;
-            z[w] = s;
-            save_z[(size_t)n * Wd + w] = s;
+    // fc1: SE_PB hidden units per round; a thread owns channels tid, tid + 256, ... and issues every weight load of the
+    // round at once (one memory round trip per round instead of one per hidden unit), then a fixed-order block sum
+    for (int w0 = 0; w0 < Wd; w0 += SE_PB) {
+        const float bv = (tid < SE_PB && w0 + tid < Wd) ? b1[w0 + tid] : 0.f;
+        float p[SE_PB];
+#pragma unroll
+        for (int u = 0; u < SE_PB; ++u) p[u] = 0.f;
+        for (int c = tid; c < C; c += 256) {
+            const float pc = pool[c];
+#pragma unroll
+            for (int u = 0; u < SE_PB; ++u) p[u] = fmaf(w1[(size_t)min(w0 + u, Wd - 1) * C + c], pc, p[u]);
         }
+#pragma unroll
+        for (int u = 0; u < SE_PB; ++u) {
+            const float t = wave_sum(p[u]);
+            if (lane == 0) part[u][wave] = t;
+        }
+        __syncthreads();
+        if (tid < SE_PB && w0 + tid < Wd) {
+            float t = (part[tid][0] + part[tid][1]) + (part[tid][2] + part[tid][3]) + bv;
+            t = t > 0.f ? t : 0.f;
+            z[w0 + tid] = t;
+            save_z[(size_t)n * Wd + w0 + tid] = t;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float s = b2[c];
         for (int w = 0; w < Wd; ++w) s = fmaf(w2[(size_t)c * Wd + w], z[w], s);
@@ -312,6 +328,7 @@ __global__ __launch_bounds__(256) void se_bwd_sample_kernel(
     float* __restrict__ dpool, float* __restrict__ dz2o, float* __restrict__ dz1o) {
     __shared__ float dz2[SE_MAXC];
     __shared__ float dz1[SE_MAXW];
+    __shared__ float part[SE_PB][4];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = n % S;
     for (int c = tid; c < C; c += 256) {
@@ -325,17 +342,32 @@ __global__ __launch_bounds__(256) void se_bwd_sample_kernel(
         dz2o[(size_t)n * C + c] = v;
     }
     __syncthreads();
-    for (int w = wave; w < Wd; w += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s = fmaf(w2[(size_t)c * Wd + w], dz2[c], s);
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float v = save_z[(size_t)n * Wd + w] > 0.f ? s : 0.f;
-            dz1[w] = v;
-            dz1o[(size_t)n * Wd + w] = v;
+    // fc2 backward onto the hidden units: same round structure as se_fwd_kernel's fc1 (a thread reads SE_PB consecutive
+    // floats of its channels' rows of w2)
+    for (int w0 = 0; w0 < Wd; w0 += SE_PB) {
+        const float zv = (tid < SE_PB && w0 + tid < Wd) ? save_z[(size_t)n * Wd + w0 + tid] : 0.f;
+        float p[SE_PB];
+#pragma unroll
+        for (int u = 0; u < SE_PB; ++u) p[u] = 0.f;
+        for (int c = tid; c < C; c += 256) {
+            const float dc = dz2[c];
+#pragma unroll
+            for (int u = 0; u < SE_PB; ++u) p[u] = fmaf(w2[(size_t)c * Wd + min(w0 + u, Wd - 1)], dc, p[u]);
         }
+#pragma unroll
+        for (int u = 0; u < SE_PB; ++u) {
+            const float t = wave_sum(p[u]);
+            if (lane == 0) part[u][wave] = t;
+        }
+        __syncthreads();
+        if (tid < SE_PB && w0 + tid < Wd) {
+            const float t = (part[tid][0] + part[tid][1]) + (part[tid][2] + part[tid][3]);
+            const float v = zv > 0.f ? t : 0.f;
+            dz1[w0 + tid] = v;
+            dz1o[(size_t)n * Wd + w0 + tid] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float s = 0.f;
         for (int w = 0; w < Wd; ++w) s = fmaf(w1[(size_t)w * C + c], dz1[w], s);
