@@ -144,7 +144,9 @@ int x3d_reduce_partials_batch(const float* const* partials, float* const* outs, 
  * ---------------------------------------------------------------------------------- */
 int x3d_dw_tiles(int H_out, int W_out);  /* spatial tiles per (n,c) used for `partial` */
 
-/* y = dw333(relu(pre*x+pre) zero-padded).  partial: float[N][C][tiles][2] {sum y, sum y^2}. */
+/* y = dw333(relu(pre*x+pre) zero-padded).  partial: float[N][C][tiles][2] {sum y, sum y^2}.
+ * pre_act of the channelwise entries: X3D_ACT_RELU or X3D_ACT_NONE only (x3d.py:147-150: ReLU precedes conv2);
+ * X3D_ACT_SWISH returns X3D_EINVAL. */
 int x3d_dw333_fwd(const float* x, const float* w, float* y,
                   int N, int C, int T, int H, int W, int strideHW,
                   const float* pre, int pre_act, float* partial, void* stream);

@@ -130,23 +130,26 @@ __device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chu
 
 // activation applied while storing; everything outside the tensor is exact zero
 template <int NCH, bool VEC>
-__device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], bool tvalid, int act,
+__device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], bool tvalid, float act_lo,
                                           const float4 (&reg)[NCH]) {
+    // Branch-free: the activation in front of this conv is ReLU (x3d.py:147-150) or none, i.e. max(s, act_lo) with
+    // act_lo = 0 / -inf (uniform); every element is computed (the registers hold real data from clamped addresses) and
+    // the invalid ones are selected to the exact zero of the padding.  The stencils are VALU / issue bound: per-element
+    // lane branches and the activation switch were a fifth of the instructions of a T step.
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        if (ch[i].loff >= 0) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tvalid && ch[i].goff >= 0) {
-                const float sc = ch[i].sc, sh = ch[i].sh;
-                v.x = act_fwd(fmaf(sc, reg[i].x, sh), act);
-                if (VEC || ch[i].nval > 1) v.y = act_fwd(fmaf(sc, reg[i].y, sh), act);
-                if (VEC || ch[i].nval > 2) v.z = act_fwd(fmaf(sc, reg[i].z, sh), act);
-                if (VEC || ch[i].nval > 3) v.w = act_fwd(fmaf(sc, reg[i].w, sh), act);
-            }
-            *reinterpret_cast<float4*>(slot + ch[i].loff) = v;
-        }
+        const int nv = (tvalid && ch[i].goff >= 0) ? (VEC ? 4 : ch[i].nval) : 0;
+        const float sc = ch[i].sc, sh = ch[i].sh;
+        float4 v;
+        v.x = nv > 0 ? fmaxf(fmaf(sc, reg[i].x, sh), act_lo) : 0.f;
+        v.y = nv > 1 ? fmaxf(fmaf(sc, reg[i].y, sh), act_lo) : 0.f;
+        v.z = nv > 2 ? fmaxf(fmaf(sc, reg[i].z, sh), act_lo) : 0.f;
+        v.w = nv > 3 ? fmaxf(fmaf(sc, reg[i].w, sh), act_lo) : 0.f;
+        if (ch[i].loff >= 0) *reinterpret_cast<float4*>(slot + ch[i].loff) = v;
     }
 }
+
+__device__ __forceinline__ float dw_act_lo(int act) { return act == X3D_ACT_RELU ? 0.f : -__builtin_inff(); }
 
 // Forward.  LDS holds two planes (double buffer); every thread keeps the values of the three
 // planes its stencil touches in registers (sliding window along T), so each staged value is
@@ -261,9 +264,10 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     } else {
         __syncthreads();
     }
-    store_act<NCH, VEC>(ring, ch, true, A.pre_act, reg);
+    const float act_lo = dw_act_lo(A.pre_act);
+    store_act<NCH, VEC>(ring, ch, true, act_lo, reg);
     fetch4<NCH, VEC>(xb, ch, plane, g.T > 1, reg);
-    store_act<NCH, VEC>(ring + g.slot, ch, g.T > 1, A.pre_act, reg);
+    store_act<NCH, VEC>(ring + g.slot, ch, g.T > 1, act_lo, reg);
     __syncthreads();
 
     // LDS offset of this thread's first window element
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
         }
         if (t == 5) DTR(3);
         // slot t&1 held plane t, last read one barrier ago -> free for plane t+2
-        store_act<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, A.pre_act, reg);
+        store_act<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, act_lo, reg);
         if (t == 5) DTR(4);
         if (valid) {
             float* py = A.y + ybase + (size_t)t * g.Ho * g.Wo;
@@ -438,6 +442,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         wt[k] = UNI ? A.w[(size_t)c0 * 27 + k] : (valid ? A.w[(size_t)c * 27 + k] : 0.f);
         dwacc[k] = 0.f;
     }
+    const float act_lo = dw_act_lo(A.pre_act);
     float sc = 1.f, sh = 0.f;
     if (A.pre != nullptr && (UNI || valid)) { sc = A.pre[((size_t)n * g.C + c) * 2]; sh = A.pre[((size_t)n * g.C + c) * 2 + 1]; }
 
@@ -586,8 +591,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             for (int i = 0; i < 4; ++i) {
                 const float sv = fmaf(sc, xv[i], sh);
                 const bool in = (w0 + i) < g.W;
-                hin[i] = in ? act_fwd(sv, A.pre_act) : 0.f;
-                dact[i] = in ? act_bwd(sv, A.pre_act) : 0.f;
+                hin[i] = in ? fmaxf(sv, act_lo) : 0.f;                 // ReLU or none (see store_act)
+                dact[i] = (in && sv > act_lo) ? 1.f : 0.f;
             }
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
@@ -753,6 +758,7 @@ extern "C" int x3d_dw333_fwd(const float* x, const float* w, float* y, int N, in
     X3D_CHECK_ARG(x && w && y);
     X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
+    X3D_CHECK_ARG(pre_act == X3D_ACT_NONE || pre_act == X3D_ACT_RELU);     // x3d.py:147-150: ReLU precedes conv2
     DwFwdArgs A;
     A.x = x; A.w = w; A.y = y; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE; A.partial = partial;
     A.sp = nullptr; A.stiles = 0; A.S = 1; A.count = 0; A.gamma = A.beta = nullptr; A.rmean = A.rvar = nullptr;
@@ -774,6 +780,7 @@ extern "C" int x3d_dw333_fwd_stats(const float* x, const float* w, float* y, int
     X3D_CHECK_ARG(x && w && y && spartial && gamma && beta && save && coef_out);
     X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0 && stiles > 0 && count > 0);
     X3D_CHECK_ARG(S > 0 && N % S == 0 && (strideHW == 1 || strideHW == 2));
+    X3D_CHECK_ARG(pre_act == X3D_ACT_NONE || pre_act == X3D_ACT_RELU);     // x3d.py:147-150: ReLU precedes conv2
     X3D_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
     DwFwdArgs A;
     A.x = x; A.w = w; A.y = y; A.pre = nullptr; A.pre_act = pre_act; A.partial = partial;
@@ -795,6 +802,7 @@ extern "C" int x3d_dw333_bwd(const float* g, const float* a, const float* cb, co
     X3D_CHECK_ARG(g && a && cb && w && x && out && wpartial);
     X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
+    X3D_CHECK_ARG(pre_act == X3D_ACT_NONE || pre_act == X3D_ACT_RELU);     // x3d.py:147-150: ReLU precedes conv2
     DwBwdArgs A;
     A.g = g; A.a = a; A.cb = cb; A.w = w; A.x = x; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE;
     A.out = out; A.wpartial = wpartial; A.partial = partial;
@@ -815,6 +823,7 @@ extern "C" int x3d_dw333_bwd_stats(const float* g, const float* a, const float* 
     X3D_CHECK_ARG(g && a && spartial && gamma && save && dgamma && dbeta && w && x && out && wpartial);
     X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0 && stiles > 0 && count > 0);
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
+    X3D_CHECK_ARG(pre_act == X3D_ACT_NONE || pre_act == X3D_ACT_RELU);     // x3d.py:147-150: ReLU precedes conv2
     DwBwdArgs A;
     A.g = g; A.a = a; A.cb = nullptr; A.w = w; A.x = x; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE;
     A.out = out; A.wpartial = wpartial; A.partial = partial;
