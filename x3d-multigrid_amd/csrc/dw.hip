@@ -118,12 +118,15 @@ __device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chu
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const bool ok = tvalid && ch[i].goff >= 0;
-        const float* p = base + (ok ? ch[i].goff + toff : 0);
         if (VEC) {
-            reg[i] = *reinterpret_cast<const float4*>(p);
+            reg[i] = *reinterpret_cast<const float4*>(base + (ok ? ch[i].goff + toff : 0));
         } else {
-            const int nv = ok ? ch[i].nval : 1;
-            reg[i] = make_float4(p[0], p[nv > 1 ? 1 : 0], p[nv > 2 ? 2 : 0], p[nv > 3 ? 3 : 0]);
+            // element offsets depend on the chunk only (hoisted out of the T march); a chunk that is not loaded reads
+            // elements 0..3 of the sample (nval <= 4 <= the sample's size)
+            const int nv = ch[i].nval;
+            const unsigned o = ok ? (unsigned)(ch[i].goff + toff) : 0u;
+            reg[i] = make_float4(base[o], base[o + (nv > 1 ? 1u : 0u)], base[o + (nv > 2 ? 2u : 0u)],
+                                 base[o + (nv > 3 ? 3u : 0u)]);
         }
     }
 }
