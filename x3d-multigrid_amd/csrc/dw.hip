@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             const float4 qv = *reinterpret_cast<const float4*>(px);
             xnext[0] = qv.x; xnext[1] = qv.y; xnext[2] = qv.z; xnext[3] = qv.w;
         } else {
-            const int rem = ok ? g.W - w0 : 1;
+            const int rem = g.W - w0;          // independent of t: hoisted (a step that is not loaded reads elements 0..3 of x)
             xnext[0] = px[0]; xnext[1] = px[rem > 1 ? 1 : 0]; xnext[2] = px[rem > 2 ? 2 : 0]; xnext[3] = px[rem > 3 ? 3 : 0];
 #pragma unroll
             for (int i = 1; i < 4; ++i) xnext[i] = i < rem ? xnext[i] : 0.f;
