@@ -19,8 +19,15 @@ N, C, T, H, W, s = shapes[which]
 x = torch.randn(N, C, T, H, W, device=dev)
 w = torch.randn(C, 1, 3, 3, 3, device=dev)
 pre = torch.rand(N, C, 2, device=dev)
-for _ in range(5):
-    ops.dw333_fwd(x, w, stride=s, pre=pre)
+bwd = len(sys.argv) > 2 and sys.argv[2] == "bwd"
+if bwd:
+    y, _ = ops.dw333_fwd(x, w, stride=s, pre=pre)
+    gy, cb = torch.randn_like(y), torch.rand(N, C, 3, device=dev)
+    for _ in range(5):
+        ops.dw333_bwd(gy, y, cb, w, x, stride=s, pre=pre, reduce=False)
+else:
+    for _ in range(5):
+        ops.dw333_fwd(x, w, stride=s, pre=pre)
 torch.cuda.synchronize()
 buf = np.zeros(16384 * 8, dtype=np.uint64)
 rc = _lib.lib().x3d_debug_dwtrace(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
@@ -29,7 +36,7 @@ tr = buf.reshape(-1, 8)
 tr = tr[tr[:, 0] > 0].astype(np.int64)
 t0 = tr[:, 0].min()
 rel = (tr - t0) * 10
-print("case", which, "workgroups", len(tr), "span %.1f us" % (rel[:, 7].max() / 1000))
+print("case", which, "bwd" if bwd else "fwd", "workgroups", len(tr), "span %.1f us" % (rel[:, 7].max() / 1000))
 names = ["start", "prologue done", "step5 begin", "step5 stencil done", "step5 LDS staged", "step5 barrier passed", "loop done", "end"]
 for i in range(8):
     v = rel[:, i]

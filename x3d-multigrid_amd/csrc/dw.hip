@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     const float* xb = A.x + (size_t)n * g.C * g.T * g.H * g.W;
     const int plane = g.H * g.W;
 
-    float4 reg[NCH];
-    fetch4<NCH, VEC>(xb, ch, 0, true, reg);              // needs addresses only: in flight during the statistics below
+    float4 reg[NCH], reg1[NCH];
+    fetch4<NCH, VEC>(xb, ch, 0, true, reg);              // need addresses only: in flight during the statistics below
+    fetch4<NCH, VEC>(xb, ch, plane, g.T > 1, reg1);      // (planes 0 and 1 together: one round trip less)
     if (A.sp != nullptr) {
         // BN finalize of this workgroup's channels for sample n's split (x3d.py:47-58): fp64 sums over N/S samples x
         // stiles partial pairs in a fixed order (identical in every workgroup of a (split, channel)); the tile-0
@@ -269,8 +270,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     }
     const float act_lo = dw_act_lo(A.pre_act);
     store_act<NCH, VEC>(ring, ch, true, act_lo, reg);
-    fetch4<NCH, VEC>(xb, ch, plane, g.T > 1, reg);
-    store_act<NCH, VEC>(ring + g.slot, ch, g.T > 1, act_lo, reg);
+    store_act<NCH, VEC>(ring + g.slot, ch, g.T > 1, act_lo, reg1);
     __syncthreads();
 
     // LDS offset of this thread's first window element
@@ -422,6 +422,10 @@ __device__ __forceinline__ void store_dy(float* slot, const Chunk (&ch)[NCH], bo
 template <int NCH, int STRIDE, bool UNI, bool VEC>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef X3D_TRACE
+    unsigned long long dtr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    DTR(0);
     constexpr int NV = (STRIDE == 1) ? 18 : 6;           // window values per plane
     const DwGeom& g = A.geo;
     const int tid = threadIdx.x;
@@ -522,10 +526,13 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     } else {
         __syncthreads();
     }
-    store_dy<NCH, VEC>(ring, ch, true, k0, k1, k2, rg, ra);
-    fetch4<NCH, VEC>(gb, ch, plane_o, g.T > 1, rg);
-    fetch4<NCH, VEC>(ab, ch, plane_o, g.T > 1, ra);
-    store_dy<NCH, VEC>(ring + g.slot, ch, g.T > 1, k0, k1, k2, rg, ra);
+    {
+        float4 rg1[NCH], ra1[NCH];                       // plane 1 requested before plane 0 is staged: one round trip less
+        fetch4<NCH, VEC>(gb, ch, plane_o, g.T > 1, rg1);
+        fetch4<NCH, VEC>(ab, ch, plane_o, g.T > 1, ra1);
+        store_dy<NCH, VEC>(ring, ch, true, k0, k1, k2, rg, ra);
+        store_dy<NCH, VEC>(ring + g.slot, ch, g.T > 1, k0, k1, k2, rg1, ra1);
+    }
     __syncthreads();
 
     // window layout.  stride 1: rows ho = h+1-kh (kh = 0,1,2) -> staged rows row+2-kh, 6 columns
@@ -582,6 +589,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
 
     // window planes (wa, wb, wc) = dY planes (t-1, t, t+1); time tap kt uses plane t+1-kt
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
+        if (t == 5) DTR(2);
         fetch4<NCH, VEC>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, rg);
         fetch4<NCH, VEC>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, ra);
         float xv[4] = {xnext[0], xnext[1], xnext[2], xnext[3]};      // loaded one step ago, complete since the last LDS staging
@@ -646,8 +654,10 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
                 s2 = fmaf(o[i], xv[i], s2);
             }
         }
+        if (t == 5) DTR(3);
         // all loads of this step (dY plane t+2, x of step t+1) are consumed before the output store is issued
         store_dy<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, k0, k1, k2, rg, ra);
+        if (t == 5) DTR(4);
         if (valid) {
             float* po = A.out + xbase + (size_t)t * g.H * g.W;
             if (VEC) {
@@ -658,6 +668,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             }
         }
         __syncthreads();
+        if (t == 5) DTR(5);
     };
 
     float wv0[NV], wv1[NV], wv2[NV];
@@ -665,11 +676,13 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     for (int i = 0; i < NV; ++i) { wv0[i] = 0.f; wv1[i] = 0.f; wv2[i] = 0.f; }
     if (valid) read_plane(ring, wv1);                    // dY plane 0
     __syncthreads();       // step 0 overwrites slot 0: every wave must have read plane 0 first
+    DTR(1);
     for (int t = 0; t < g.T; t += 3) {
         step(t, wv0, wv1, wv2);
         if (t + 1 < g.T) step(t + 1, wv1, wv2, wv0);
         if (t + 2 < g.T) step(t + 2, wv2, wv0, wv1);
     }
+    DTR(6);
 
     // reductions: per channel of the block, over its ipc items, in item order
     float* rb = lds;    // reuse the ring: [29][256]
@@ -681,13 +694,25 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     for (int o = tid; o < g.cpb * 29; o += 256) {
         const int chn = o / 29, k = o - chn * 29;
         if (c0 + chn < g.C) {
-            float s = 0.f;
-            for (int i = 0; i < g.ipc; ++i) s += rb[k * 256 + chn * g.ipc + i];
+            // four interleaved partial sums (fixed order): the LDS reads of a round are independent
+            const float* rp = rb + k * 256 + chn * g.ipc;
+            float s0 = 0.f, s1_ = 0.f, s2_ = 0.f, s3 = 0.f;
+            int i = 0;
+            for (; i + 3 < g.ipc; i += 4) { s0 += rp[i]; s1_ += rp[i + 1]; s2_ += rp[i + 2]; s3 += rp[i + 3]; }
+            for (; i < g.ipc; ++i) s0 += rp[i];
+            const float s = (s0 + s1_) + (s2_ + s3);
             const size_t row_id = ((size_t)n * g.C + c0 + chn) * g.tiles + tile;
             if (k < 27) A.wpartial[(((size_t)n * g.tiles + tile) * g.C + c0 + chn) * 27 + k] = s;   // [N][tiles][C][27]
             else if (A.partial != nullptr) A.partial[row_id * 2 + (k - 27)] = s;
         }
     }
+#ifdef X3D_TRACE
+    if (tid == 0) {
+        dtr[7] = wall_clock64();
+        const size_t id = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (id < 16384) for (int i = 0; i < 8; ++i) g_dwtrace[id * 8 + i] = dtr[i];
+    }
+#endif
 }
 
 static size_t fwd_lds_bytes(const DwGeom& g) { return (2 * (size_t)g.slot + 512) * sizeof(float); }
