@@ -1505,7 +1505,12 @@ static void pw_plan(int N, int K, int M, int P, bool dense, int* variant, int* t
     int v = (dense && (P % 4 == 0)) ? 4 : 1;
     if (v == 4) {
         const long long wgs = (long long)cdiv(P, 256) * N * (*mblocks);
-        if (wgs < 1024) v = 1;      // small-P layers: 16 voxels per wave fills the chip (4x the waves)
+        // small-P layers: 16 voxels per wave (NT = 1) gives 4x the waves -- but the float4 form moves the same bytes with
+        // a quarter of the memory instructions and wins as soon as its workgroups cover the CUs (stage 2 at the base
+        // shape: 392 / 784 workgroups, +1.4 % on the step), unless the last 256-voxel tile of a sample is mostly empty
+        static const long long nt4_min = getenv("X3D_PW_NT4_MIN") ? atoll(getenv("X3D_PW_NT4_MIN")) : 256;
+        const bool full_tiles = (long long)P * 10 >= (long long)cdiv(P, 256) * 256 * 9;
+        if (wgs < nt4_min || (wgs < 1024 && !full_tiles)) v = 1;
     }
     *variant = v == 4 ? 0 : 1;
     *tiles = cdiv(P, 64 * v);
