@@ -1524,7 +1524,8 @@ int launch_pw(PwArgs& A, hipStream_t s) {
     dim3 grid(cdiv(A.tiles, 8) * 8 * A.mblocks, A.N), block(256);
     if (variant == 3 && A.wp != nullptr) {
         const int items = cdiv(A.tiles * A.N, 8) * 8 * A.mblocks;
-        dim3 pgrid(min(items, 512));            // two resident workgroups per CU walk the item list
+        static const int pg_max = getenv("X3D_PW_PGRID") ? atoi(getenv("X3D_PW_PGRID")) : 512;
+        dim3 pgrid(min(items, pg_max));         // two resident workgroups per CU walk the item list
         const int U = cdiv(A.mt_run, 2);
         if (IN == IN_BNBWD && EPI != EPI_STATS && getenv("X3D_DGRAD_F32") == nullptr) {
             // backward-data: split-bf16 MFMA (the transposed pack carries the bf16 planes)
