@@ -41,10 +41,13 @@ static DwGeom make_geom(int N, int C, int T, int H, int W, int stride, bool back
     g.Wo = stride == 2 ? (W - 1) / 2 + 1 : W;
     const int GH = backward ? H : g.Ho, GW = backward ? W : g.Wo;   // thread grid
     g.groups = cdiv(GW, 4);
+    static const int th_max = getenv("X3D_DW_TH") ? atoi(getenv("X3D_DW_TH")) : DW_TH;
+    static const bool balance = getenv("X3D_DW_BALANCE") == nullptr || atoi(getenv("X3D_DW_BALANCE")) != 0;   // default on: +0.6 %
     int th = 256 / g.groups;
     if (th < 1) th = 1;
-    if (th > DW_TH) th = DW_TH;
+    if (th > th_max) th = th_max;
     if (th > GH) th = GH;
+    if (balance) th = cdiv(GH, cdiv(GH, th));          // equal tile heights (same tile count)
     if (backward && stride == 2 && th > 1 && (th & 1)) th -= 1;   // even tile origin in backward stride 2
     g.TH = th;
     g.ipc = th * g.groups;
