@@ -248,7 +248,14 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ c
     }
     for (int c = tid; c < C; c += 256) {
         float s = b2[c];
-        for (int w = 0; w < Wd; ++w) s = fmaf(w2[(size_t)c * Wd + w], z[w], s);
+        if ((Wd & 3) == 0) {          // 16-byte loads along the channel's row (see se_bwd_sample_kernel)
+            for (int w = 0; w < Wd; w += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(w2 + (size_t)c * Wd + w);
+                s = fmaf(v.x, z[w], s); s = fmaf(v.y, z[w + 1], s); s = fmaf(v.z, z[w + 2], s); s = fmaf(v.w, z[w + 3], s);
+            }
+        } else {
+            for (int w = 0; w < Wd; ++w) s = fmaf(w2[(size_t)c * Wd + w], z[w], s);
+        }
         const float se = sigmoidf_(s);
         save_se[(size_t)n * C + c] = se;
         coef_out[((size_t)n * C + c) * 2] = coef[((size_t)n * C + c) * 2] * se;
@@ -349,10 +356,27 @@ __global__ __launch_bounds__(256) void se_bwd_sample_kernel(
         float p[SE_PB];
 #pragma unroll
         for (int u = 0; u < SE_PB; ++u) p[u] = 0.f;
-        for (int c = tid; c < C; c += 256) {
-            const float dc = dz2[c];
+        if ((Wd & 3) == 0) {
+            // a thread's 16 weights are consecutive in its channel's row: four 16-byte loads instead of sixteen dword
+            // loads that each touch 64 different cache lines (the rows are Wd floats apart across the lanes)
+            for (int c = tid; c < C; c += 256) {
+                const float dc = dz2[c];
 #pragma unroll
-            for (int u = 0; u < SE_PB; ++u) p[u] = fmaf(w2[(size_t)c * Wd + min(w0 + u, Wd - 1)], dc, p[u]);
+                for (int q4 = 0; q4 < SE_PB / 4; ++q4) {
+                    const int wq = min(w0 + 4 * q4, Wd - 4);                 // clamped: products of repeated columns land
+                    const float4 v = *reinterpret_cast<const float4*>(w2 + (size_t)c * Wd + wq);   // in p[u] with w0+u >= Wd,
+                    p[4 * q4] = fmaf(v.x, dc, p[4 * q4]);                    // which are never read
+                    p[4 * q4 + 1] = fmaf(v.y, dc, p[4 * q4 + 1]);
+                    p[4 * q4 + 2] = fmaf(v.z, dc, p[4 * q4 + 2]);
+                    p[4 * q4 + 3] = fmaf(v.w, dc, p[4 * q4 + 3]);
+                }
+            }
+        } else {
+            for (int c = tid; c < C; c += 256) {
+                const float dc = dz2[c];
+#pragma unroll
+                for (int u = 0; u < SE_PB; ++u) p[u] = fmaf(w2[(size_t)c * Wd + min(w0 + u, Wd - 1)], dc, p[u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < SE_PB; ++u) {
