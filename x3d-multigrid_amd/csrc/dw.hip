@@ -727,13 +727,15 @@ static int nch_for(const DwGeom& g) { return cdiv(g.cpb * g.IH * (g.WP / 4 - 2),
 
 }  // namespace
 
-extern "C" int x3d_dw_tiles(int H_out, int W_out) {
-    DwGeom g = make_geom(1, 1, 1, H_out, W_out, 1, false);
+// The tile height depends on N and C too (whole rounds of workgroups, make_geom): the queries take the same N, C as the
+// launch they size buffers for.
+extern "C" int x3d_dw_tiles(int N, int C, int H_out, int W_out) {
+    DwGeom g = make_geom(N, C, 1, H_out, W_out, 1, false);
     return g.tiles;
 }
 
-extern "C" int x3d_dw_bwd_tiles(int H, int W, int strideHW) {
-    DwGeom g1 = make_geom(1, 1, 1, H, W, strideHW == 2 ? 2 : 1, true);
+extern "C" int x3d_dw_bwd_tiles(int N, int C, int H, int W, int strideHW) {
+    DwGeom g1 = make_geom(N, C, 1, H, W, strideHW == 2 ? 2 : 1, true);
     return g1.tiles;
 }
 
