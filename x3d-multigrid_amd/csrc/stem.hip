@@ -32,7 +32,24 @@ __global__ __launch_bounds__(256) void stem133_fwd_kernel(const float* __restric
             }
         }
     }
-    for (int co = 0; co < Cout; ++co) {
+    // four output channels per round: their 4 x 27 wave-uniform weights are fetched by one batch of scalar loads and the
+    // four FMA chains are independent (a single chain waits for each scalar load batch and for its own FMA latency)
+    int co = 0;
+    for (; co + 3 < Cout; co += 4) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float* wc = w + (size_t)co * CIN * 9;
+#pragma unroll
+        for (int k = 0; k < CIN * 9; ++k) {
+            s0 = fmaf(wc[k], v[k], s0);
+            s1 = fmaf(wc[CIN * 9 + k], v[k], s1);
+            s2 = fmaf(wc[2 * CIN * 9 + k], v[k], s2);
+            s3 = fmaf(wc[3 * CIN * 9 + k], v[k], s3);
+        }
+        float* py = y + (((size_t)n * Cout + co) * T + t) * (size_t)Ho * Wo + p;
+        const size_t cs = (size_t)T * Ho * Wo;
+        py[0] = s0; py[cs] = s1; py[2 * cs] = s2; py[3 * cs] = s3;
+    }
+    for (; co < Cout; ++co) {
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < CIN * 9; ++k) s = fmaf(w[co * CIN * 9 + k], v[k], s);
