@@ -111,12 +111,25 @@ __device__ __forceinline__ void channel_row_sums(const float* __restrict__ parti
         const int n = n0 + sub;
         const bool ok = n < N;
         const float* p = partial + ((size_t)(ok ? n : 0) * C + c) * tiles * 2;      // clamped: no load under a lane branch
-        double a = 0.0, b = 0.0;
-        for (int t = l; t < tiles; t += G) {
-            const float2 v = *reinterpret_cast<const float2*>(p + 2 * t);
-            a += (double)v.x;
-            b += (double)v.y;
+        // four loads in flight per lane (a row of 784 tile pairs was twelve serial round trips); fixed order
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        int t = l;
+        for (; t + 3 * G < tiles; t += 4 * G) {
+            const float2 v0 = *reinterpret_cast<const float2*>(p + 2 * t);
+            const float2 v1 = *reinterpret_cast<const float2*>(p + 2 * (t + G));
+            const float2 v2 = *reinterpret_cast<const float2*>(p + 2 * (t + 2 * G));
+            const float2 v3 = *reinterpret_cast<const float2*>(p + 2 * (t + 3 * G));
+            a0 += (double)v0.x; b0 += (double)v0.y;
+            a1 += (double)v1.x; b1 += (double)v1.y;
+            a2 += (double)v2.x; b2 += (double)v2.y;
+            a3 += (double)v3.x; b3 += (double)v3.y;
         }
+        for (; t < tiles; t += G) {
+            const float2 v = *reinterpret_cast<const float2*>(p + 2 * t);
+            a0 += (double)v.x;
+            b0 += (double)v.y;
+        }
+        double a = (a0 + a1) + (a2 + a3), b = (b0 + b1) + (b2 + b3);
         for (int o = G >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
         if (l == 0 && ok) { rows[2 * n] = a; rows[2 * n + 1] = b; }
     }
