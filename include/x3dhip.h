@@ -281,6 +281,11 @@ int x3d_bn_relu_pool_fwd(const float* a5, const float* c5, float* pooled,
 int x3d_bn_relu_pool_bwd(const float* a5, const float* c5, const float* dpooled,
                          float* g, float* partial, int N, int C, int P, int segs, void* stream);
 
+/* Gradient accumulation over micro-batches (`loss = cls_loss / num_steps_per_update; loss.backward()` repeated
+ * num_steps_per_update times before optimizer.step(), train_x3d_kinetics_multigrid.py:119,267-273):
+ * acc = (first ? 0 : acc) + scale * g over the flat gradient buffer. */
+int x3d_grad_accumulate(float* acc, const float* g, size_t n, float scale, int first, void* stream);
+
 /* Fused SGD (torch.optim.SGD, train_x3d_kinetics_multigrid.py:183): g += wd*w;
  * m = first ? g : mu*m + g; w -= lr*m.  grad_scale multiplies g first (1/world_size). */
 int x3d_sgd_fused(float* w, const float* g, float* m, size_t n, float lr, float momentum,

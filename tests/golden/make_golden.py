@@ -215,6 +215,12 @@ def main():
     }
     if args.big:
         jobs["train_M_8x16x224_s1"] = lambda: train_case(ref, "M", 8, 16, 224, 1)
+        # BASELINE config 3 at full per-GPU batch (kinetics_multigrid.py:205-237 x cycle_batch_sampler.py:98-111):
+        # the two literal shapes of the config with num_splits = B / 8
+        jobs["train_M_64x4x112_s8"] = lambda: train_case(ref, "M", 64, 4, 112, 8)
+        jobs["train_M_16x16x224_s2"] = lambda: train_case(ref, "M", 16, 16, 224, 2)
+    # X3D-XL widths (x3d.py:355) pinned by the reference itself on a tiny clip
+    jobs["train_XL_2x4x64_s1"] = lambda: train_case(ref, "XL", 2, 4, 64, 1, seed=2)
     for name, fn in jobs.items():
         if args.only and args.only != name:
             continue

@@ -513,13 +513,14 @@ constexpr int EW_TILE = 2048;   // elements per workgroup tile (256 threads x 2 
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_add_relu_fwd_kernel(const float* __restrict__ a3, const float* __restrict__ c3,
                                                               const float* __restrict__ res, const float* __restrict__ cd,
-                                                              float* __restrict__ out, int P) {
-    const int row = blockIdx.y;
+                                                              float* __restrict__ out, int P, int ewt) {
+    // 1-D grid (rows x tiles, tile fastest): N * C is not bounded by the 65535 limit of grid.y
+    const int row = blockIdx.x / ewt, tix = blockIdx.x - row * ewt;
     const float sc = c3[(size_t)row * 2], sh = c3[(size_t)row * 2 + 1];
     float rc = 1.f, rh = 0.f;
     if (cd != nullptr) { rc = cd[(size_t)row * 2]; rh = cd[(size_t)row * 2 + 1]; }
     const size_t base = (size_t)row * P;
-    const int p0 = blockIdx.x * EW_TILE;
+    const int p0 = tix * EW_TILE;
     if (VEC) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -552,12 +553,12 @@ __global__ __launch_bounds__(256) void bn_stats_add_relu_fwd_kernel(
     const float* __restrict__ a3, const float* __restrict__ partial, int tiles, int N, int C, int S, int count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
     float momentum, float eps, float* __restrict__ save, const float* __restrict__ res, const float* __restrict__ cd,
-    float* __restrict__ out, int P) {
+    float* __restrict__ out, int P, int ewt) {
     __shared__ double redd[4 * 2];
-    const int row = blockIdx.y, tid = threadIdx.x;
+    const int row = blockIdx.x / ewt, tix = blockIdx.x - row * ewt, tid = threadIdx.x;
     const int n = row / C, c = row - n * C, j = n % S;
     const size_t base = (size_t)row * P;
-    const int p0 = blockIdx.x * EW_TILE;
+    const int p0 = tix * EW_TILE;
     // 1. the streaming reads do not depend on the statistics: issue them first
     float4 av[2], rv[2];
     if (VEC) {
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(256) void bn_stats_add_relu_fwd_kernel(
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const float sc = (float)((double)gamma[c] * invstd);
     const float sh = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
-    if (blockIdx.x == 0 && n == j && tid == 0) {
+    if (tix == 0 && n == j && tid == 0) {
         save[(size_t)j * C + c] = (float)mean;
         save[(size_t)(S + j) * C + c] = (float)invstd;
         if (rmean != nullptr) {
@@ -627,9 +628,9 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __res
                                                               float* __restrict__ g, float* __restrict__ partial,
                                                               float* __restrict__ partial_d, int P, int tiles) {
     __shared__ float red[4 * 3];
-    const int row = blockIdx.y;
+    const int row = blockIdx.x / tiles, tix = blockIdx.x - row * tiles;
     const size_t base = (size_t)row * P;
-    const int p0 = blockIdx.x * EW_TILE;
+    const int p0 = tix * EW_TILE;
     float v[3] = {0.f, 0.f, 0.f};
     if (VEC) {
 #pragma unroll
@@ -665,11 +666,11 @@ __global__ __launch_bounds__(256) void bn_add_relu_bwd_kernel(const float* __res
     float o3[3];
     block_sum_256<3>(v, red, o3);
     if (threadIdx.x == 0) {
-        partial[((size_t)row * tiles + blockIdx.x) * 2] = o3[0];
-        partial[((size_t)row * tiles + blockIdx.x) * 2 + 1] = o3[1];
+        partial[((size_t)row * tiles + tix) * 2] = o3[0];
+        partial[((size_t)row * tiles + tix) * 2 + 1] = o3[1];
         if (partial_d != nullptr) {
-            partial_d[((size_t)row * tiles + blockIdx.x) * 2] = o3[0];
-            partial_d[((size_t)row * tiles + blockIdx.x) * 2 + 1] = o3[2];
+            partial_d[((size_t)row * tiles + tix) * 2] = o3[0];
+            partial_d[((size_t)row * tiles + tix) * 2 + 1] = o3[2];
         }
     }
 }
@@ -694,12 +695,12 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
                                                                const float* __restrict__ dpooled, float* __restrict__ g,
                                                                float* __restrict__ partial, int P, int tiles, int segs) {
     __shared__ float red[4 * 2];
-    const int row = blockIdx.y;
+    const int row = blockIdx.x / tiles, tix = blockIdx.x - row * tiles;
     const int Ps = P / segs;
     const float sc = c5[(size_t)row * 2], sh = c5[(size_t)row * 2 + 1];
     const float inv = 1.f / (float)Ps;
     const size_t base = (size_t)row * P;
-    const int p0 = blockIdx.x * EW_TILE;
+    const int p0 = tix * EW_TILE;
     float v[2] = {0.f, 0.f};
     for (int p = p0 + threadIdx.x; p < min(P, p0 + EW_TILE); p += 256) {
         const float a = a5[base + p];
@@ -712,8 +713,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
     float o[2];
     block_sum_256<2>(v, red, o);
     if (threadIdx.x == 0) {
-        partial[((size_t)row * tiles + blockIdx.x) * 2] = o[0];
-        partial[((size_t)row * tiles + blockIdx.x) * 2 + 1] = o[1];
+        partial[((size_t)row * tiles + tix) * 2] = o[0];
+        partial[((size_t)row * tiles + tix) * 2 + 1] = o[1];
     }
 }
 
@@ -726,6 +727,15 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const f
     const float mi = first ? gi : fmaf(mu, m[i], gi);
     m[i] = mi;
     w[i] = wi - lr * mi;
+}
+
+// acc = (first ? 0 : acc) + scale * g  (gradient accumulation over micro-batches: loss / num_steps_per_update,
+// train_x3d_kinetics_multigrid.py:267-273)
+__global__ __launch_bounds__(256) void grad_accumulate_kernel(float* __restrict__ acc, const float* __restrict__ g, size_t n,
+                                                              float scale, int first) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    acc[i] = first ? scale * g[i] : fmaf(scale, g[i], acc[i]);
 }
 
 }  // namespace
@@ -827,13 +837,13 @@ extern "C" int x3d_se_bn_bwd_finalize(const float* partial, int N, int C, int ti
 extern "C" int x3d_bn_add_relu_fwd(const float* a3, const float* c3, const float* res, const float* cd, float* out,
                                    int N, int C, int P, void* stream) {
     X3D_CHECK_ARG(a3 && c3 && res && out && N > 0 && C > 0 && P > 0);
-    X3D_CHECK_ARG((long long)N * C <= 65535LL * 32768LL);
-    dim3 grid(cdiv(P, EW_TILE), N * C), block(256);
-    X3D_CHECK_ARG(N * C <= 65535);
+    const int ewt = cdiv(P, EW_TILE);
+    X3D_CHECK_ARG((long long)N * C * ewt <= 0x7fffffffLL);
+    dim3 grid((unsigned)(N * C * ewt)), block(256);
     if (P % 4 == 0)
-        hipLaunchKernelGGL(bn_add_relu_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a3, c3, res, cd, out, P);
+        hipLaunchKernelGGL(bn_add_relu_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a3, c3, res, cd, out, P, ewt);
     else
-        hipLaunchKernelGGL(bn_add_relu_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a3, c3, res, cd, out, P);
+        hipLaunchKernelGGL(bn_add_relu_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a3, c3, res, cd, out, P, ewt);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
@@ -843,25 +853,27 @@ extern "C" int x3d_bn_stats_add_relu_fwd(const float* a3, const float* partial, 
                                          float momentum, float eps, float* save, const float* res, const float* cd,
                                          float* out, int N, int C, int P, void* stream) {
     X3D_CHECK_ARG(a3 && partial && gamma && beta && save && res && out && N > 0 && C > 0 && P > 0 && tiles > 0);
-    X3D_CHECK_ARG(S > 0 && N % S == 0 && count > 0 && N * C <= 65535);
+    const int ewt = cdiv(P, EW_TILE);
+    X3D_CHECK_ARG(S > 0 && N % S == 0 && count > 0 && (long long)N * C * ewt <= 0x7fffffffLL);
     X3D_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
-    dim3 grid(cdiv(P, EW_TILE), N * C), block(256);
+    dim3 grid((unsigned)(N * C * ewt)), block(256);
     if (P % 4 == 0)
         hipLaunchKernelGGL(bn_stats_add_relu_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a3, partial, tiles, N, C,
-                           S, count, gamma, beta, running_mean, running_var, momentum, eps, save, res, cd, out, P);
+                           S, count, gamma, beta, running_mean, running_var, momentum, eps, save, res, cd, out, P, ewt);
     else
         hipLaunchKernelGGL(bn_stats_add_relu_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a3, partial, tiles, N, C,
-                           S, count, gamma, beta, running_mean, running_var, momentum, eps, save, res, cd, out, P);
+                           S, count, gamma, beta, running_mean, running_var, momentum, eps, save, res, cd, out, P, ewt);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
 
 extern "C" int x3d_bn_add_relu_bwd(const float* dout, const float* out, const float* a3, const float* ad, float* g,
                                    float* partial, float* partial_d, int N, int C, int P, void* stream) {
-    X3D_CHECK_ARG(dout && out && a3 && g && partial && N > 0 && C > 0 && P > 0 && N * C <= 65535);
+    X3D_CHECK_ARG(dout && out && a3 && g && partial && N > 0 && C > 0 && P > 0);
     X3D_CHECK_ARG((ad == nullptr) == (partial_d == nullptr));
     const int tiles = cdiv(P, EW_TILE);
-    dim3 grid(tiles, N * C), block(256);
+    X3D_CHECK_ARG((long long)N * C * tiles <= 0x7fffffffLL);
+    dim3 grid((unsigned)(N * C * tiles)), block(256);
     if (P % 4 == 0)
         hipLaunchKernelGGL(bn_add_relu_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, dout, out, a3, ad, g,
                            partial, partial_d, P, tiles);
@@ -883,11 +895,20 @@ extern "C" int x3d_bn_relu_pool_fwd(const float* a5, const float* c5, float* poo
 
 extern "C" int x3d_bn_relu_pool_bwd(const float* a5, const float* c5, const float* dpooled, float* g, float* partial,
                                     int N, int C, int P, int segs, void* stream) {
-    X3D_CHECK_ARG(a5 && c5 && dpooled && g && partial && N > 0 && C > 0 && P > 0 && N * C <= 65535);
+    X3D_CHECK_ARG(a5 && c5 && dpooled && g && partial && N > 0 && C > 0 && P > 0);
     X3D_CHECK_ARG(segs > 0 && P % segs == 0);
     const int tiles = cdiv(P, EW_TILE);
-    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel, dim3(tiles, N * C), dim3(256), 0, (hipStream_t)stream, a5, c5, dpooled,
+    X3D_CHECK_ARG((long long)N * C * tiles <= 0x7fffffffLL);
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel, dim3((unsigned)(N * C * tiles)), dim3(256), 0, (hipStream_t)stream, a5, c5, dpooled,
                        g, partial, P, tiles, segs);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_grad_accumulate(float* acc, const float* g, size_t n, float scale, int first, void* stream) {
+    X3D_CHECK_ARG(acc && g && n > 0);
+    hipLaunchKernelGGL(grad_accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc, g, n,
+                       scale, first);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

@@ -147,9 +147,10 @@ __global__ __launch_bounds__(256) void dw5t_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ y, int C, int T, int HW,
                                                        float* __restrict__ partial, int tiles) {
     __shared__ float red[4 * 2];
-    const int row = blockIdx.y;            // n*C + c
+    // 1-D grid (rows x tiles, tile fastest): N * C is not bounded by the 65535 limit of grid.y
+    const int row = blockIdx.x / tiles, tix = blockIdx.x - row * tiles;            // row = n*C + c
     const int c = row % C;
-    const int p = blockIdx.x * T5_TILE + threadIdx.x * 4;
+    const int p = tix * T5_TILE + threadIdx.x * 4;
     float wk[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) wk[k] = w[c * 5 + k];
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(256) void dw5t_fwd_kernel(const float* __restrict__
         float o2[2];
         block_sum_256<2>(s, red, o2);
         if (threadIdx.x == 0) {
-            partial[((size_t)row * tiles + blockIdx.x) * 2] = o2[0];
-            partial[((size_t)row * tiles + blockIdx.x) * 2 + 1] = o2[1];
+            partial[((size_t)row * tiles + tix) * 2] = o2[0];
+            partial[((size_t)row * tiles + tix) * 2 + 1] = o2[1];
         }
     }
 }
@@ -210,9 +211,9 @@ __global__ __launch_bounds__(256) void dw5t_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ x, float* __restrict__ dx,
                                                        float* __restrict__ wpartial, int C, int T, int HW, int tiles) {
     __shared__ float red[4 * 5];
-    const int row = blockIdx.y;
+    const int row = blockIdx.x / tiles, tix = blockIdx.x - row * tiles;
     const int c = row % C;
-    const int p = blockIdx.x * T5_TILE + threadIdx.x * 4;
+    const int p = tix * T5_TILE + threadIdx.x * 4;
     const float k0 = cb[(size_t)row * 3], k1 = cb[(size_t)row * 3 + 1], k2 = cb[(size_t)row * 3 + 2];
     float wk[5];
 #pragma unroll
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void dw5t_bwd_kernel(const float* __restrict__
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)   // layout [N][tiles][C][5]: a plain group sum over (n, tile) finishes it
-            wpartial[((((size_t)(row / C)) * tiles + blockIdx.x) * C + c) * 5 + k] = o5[k];
+            wpartial[((((size_t)(row / C)) * tiles + tix) * C + c) * 5 + k] = o5[k];
     }
 }
 
@@ -320,9 +321,10 @@ extern "C" int x3d_dw5t_tiles(int HW) { return cdiv(HW, T5_TILE); }
 
 extern "C" int x3d_dw5t_fwd(const float* x, const float* w, float* y, int N, int C, int T, int HW, float* partial,
                             void* stream) {
-    X3D_CHECK_ARG(x && w && y && N > 0 && C > 0 && T > 0 && HW > 0 && N * C <= 65535);
+    X3D_CHECK_ARG(x && w && y && N > 0 && C > 0 && T > 0 && HW > 0);
     const int tiles = cdiv(HW, T5_TILE);
-    dim3 grid(tiles, N * C), block(256);
+    X3D_CHECK_ARG((long long)N * C * tiles <= 0x7fffffffLL);
+    dim3 grid((unsigned)(N * C * tiles)), block(256);
     if (HW % 4 == 0)
         hipLaunchKernelGGL(dw5t_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, w, y, C, T, HW, partial, tiles);
     else
@@ -333,9 +335,10 @@ extern "C" int x3d_dw5t_fwd(const float* x, const float* w, float* y, int N, int
 
 extern "C" int x3d_dw5t_bwd(const float* g, const float* a, const float* cb, const float* w, const float* x,
                             float* dx, float* wpartial, int N, int C, int T, int HW, void* stream) {
-    X3D_CHECK_ARG(g && a && cb && w && x && dx && wpartial && N > 0 && C > 0 && T > 0 && HW > 0 && N * C <= 65535);
+    X3D_CHECK_ARG(g && a && cb && w && x && dx && wpartial && N > 0 && C > 0 && T > 0 && HW > 0);
     const int tiles = cdiv(HW, T5_TILE);
-    dim3 grid(tiles, N * C), block(256);
+    X3D_CHECK_ARG((long long)N * C * tiles <= 0x7fffffffLL);
+    dim3 grid((unsigned)(N * C * tiles)), block(256);
     if (HW % 4 == 0)
         hipLaunchKernelGGL(dw5t_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, g, a, cb, w, x, dx, wpartial, C, T,
                            HW, tiles);

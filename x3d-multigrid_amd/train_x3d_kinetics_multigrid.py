@@ -141,13 +141,24 @@ def validate(model, batches):
     return tot_cls_loss / max(num_iter, 1), tot_corr / max(tot_dat, 1), tot_dat
 
 
+def _save_ckpt(model, optimizer, lr_sched, long_ind, save_model, steps):
+    """The reference's checkpoint record (train_x3d_kinetics_multigrid.py:286-291)."""
+    ckpt = {'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict(),
+            'scheduler_state_dict': lr_sched.state_dict(), 'long_ind': long_ind}
+    os.makedirs(os.path.dirname(save_model) or '.', exist_ok=True)
+    torch.save(ckpt, save_model + str(steps).zfill(6) + '.pt')
+
+
 def run(init_lr=INIT_LR, warmup_steps=8000, max_epochs=120, batch_size=BS * BS_UPSCALE, steps=0, max_steps_run=None,
         iterations_per_epoch=None, load_ckpt=None, save_model='models/x3d_multigrid_kinetics_rgb_sgd_',
         save_every=4000, use_graph=True, x3d_version=X3D_VERSION, log_every=20, val_every=None, val_batches=2,
-        val_batch_size=2, val_crops=3):
+        val_batch_size=2, val_crops=3, num_steps_per_update=1, clip_size=None):
     """The reference's training loop (train_x3d_kinetics_multigrid.py:157-292) on synthetic clips.  val_every: run the
     validation phase (`validate`, the reference does it after every 4 training epochs, :195) every that many steps on
-    `val_batches` synthetic batches of [val_batch_size, val_crops, 3, T, H, W]."""
+    `val_batches` synthetic batches of [val_batch_size, val_crops, 3, T, H, W].
+    num_steps_per_update: gradient accumulation over that many micro-batches per optimizer step (train...:119,267-273;
+    the schedule then counts iterations and lr_schedule is divided by it, :130).  clip_size overrides the crop size of
+    the shape table (tests: the default batch arithmetic at a tiny resolution)."""
     from x3dhip.trainer import Trainer
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -165,13 +176,16 @@ def run(init_lr=INIT_LR, warmup_steps=8000, max_epochs=120, batch_size=BS * BS_U
     resize_size = {'S': [180., 225.], 'M': [256., 256.], 'XL': [360., 450.], 'L': [360., 450.]}[x3d_version]
     gamma_tau = {'S': 6, 'M': 5, 'XL': 5, 'L': 5}[x3d_version]
     st_steps = load_steps = steps
-    num_steps_per_update = 1
+    if batch_size % world != 0:
+        raise ValueError("global batch %d is not divisible by the world size %d" % (batch_size, world))
     if iterations_per_epoch is None:
         iterations_per_epoch = KINETICS_DATASET_SIZE['train'] // batch_size
     last_long = -2
 
     shapes, _, lr_schedule = setup_data(batch_size, num_steps_per_update, max_epochs, iterations_per_epoch,
                                         steps * num_steps_per_update, crop_size, resize_size, frames, gamma_tau)
+    lr_schedule = [i // num_steps_per_update for i in lr_schedule]          # train...:130
+    total_steps = lr_schedule[-1]
     if rank == 0:
         print('Total iterations:', lr_schedule[-1] * num_steps_per_update, 'Total steps:', lr_schedule[-1])
 
@@ -190,7 +204,7 @@ def run(init_lr=INIT_LR, warmup_steps=8000, max_epochs=120, batch_size=BS * BS_U
 
     lr = init_lr
     optimizer = Trainer(model, lr=lr, momentum=0.9, weight_decay=5e-5, process_group=pg, world_size=world,
-                        use_graph=use_graph)
+                        use_graph=use_graph, num_steps_per_update=num_steps_per_update)
     lr_sched = MultiStepLR(optimizer, lr_schedule)
     if ck is not None:
         optimizer.load_state_dict(ck['optimizer_state_dict'])
@@ -204,56 +218,68 @@ def run(init_lr=INIT_LR, warmup_steps=8000, max_epochs=120, batch_size=BS * BS_U
     clips = 0
     done = 0
     bn_splits = model.bn1.num_splits
-    for n_global, long_ind, (T, H) in shapes:
-        if max_steps_run is not None and done >= max_steps_run:
-            break
-        if long_ind != last_long:
-            bn_splits = model.update_bn_splits_long_cycle(LONG_CYCLE[long_ind])
-            lr_scale_fact = LONG_CYCLE[long_ind] if (last_long == -2 or long_ind == -1) else LONG_CYCLE_LR_SCALE[long_ind]
-            last_long = long_ind
-            for g in optimizer.param_groups:
-                g['lr'] *= lr_scale_fact
-                lr = g['lr']
-            if rank == 0:
-                fr, cr = cbs.long_cycle_shapes(frames, 224)[long_ind]
-                print_stats(long_ind, batch_size, (fr // gamma_tau, cr // 2, int(cr / 2 ** 0.5), cr), gamma_tau,
-                            bn_splits, lr)
-        B = n_global // world
-        inputs, labels = device_batch(B, T, H, 400, dev, gen)
-        loss, logits = optimizer.train_step(inputs, labels,
-                                            pre_step=lambda: lr_warmup(lr, steps - st_steps, warmup_steps, optimizer))
-        steps += 1
-        done += 1
-        lr_sched.step()
-        clips += n_global
-        if done % log_every == 0 or done == 1:
-            tot_loss = float(loss)
-            preds = logits.argmax(1)
-            acc = float((preds == labels).float().mean())
-            if rank == 0:
-                dt = time.time() - t0
-                print(' step {} long {} shape ({},{},{}) loss {:.4f} acc {:.3f} lr {:.5f}  {:.1f} clips/s'.format(
-                    steps, long_ind, B, T, H, tot_loss, acc, optimizer.param_groups[0]['lr'], clips / dt), flush=True)
-        if val_every and done % val_every == 0:
-            Tv, Hv = frames // gamma_tau, crop_size
-            vb = []
-            for _ in range(val_batches):
-                xv, yv = device_batch(val_batch_size * val_crops, Tv, Hv, 400, dev, gen)
-                vb.append((xv.view(val_batch_size, val_crops, 3, Tv, Hv, Hv), yv.view(-1)[:val_batch_size]))
-            v_loss, v_acc, v_seen = validate(model, vb)
-            model.train(True)                                   # train...:199-200
-            if rank == 0:
-                print(' val after step {}: Cls Loss: {:.4f} Acc: {:.4f} ({} videos)'.format(steps, v_loss, v_acc, v_seen), flush=True)
-        if save_every and steps % save_every == 0 and rank == 0:
-            ckpt = {'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict(),
-                    'scheduler_state_dict': lr_sched.state_dict(), 'long_ind': long_ind}
-            os.makedirs(os.path.dirname(save_model) or '.', exist_ok=True)
-            torch.save(ckpt, save_model + str(steps).zfill(6) + '.pt')
-    torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    long_ind = max(last_long, 0)
+    try:
+        for n_global, long_ind, (T, H) in shapes:
+            # the reference's loop ends with max_epochs (train...:192); the schedule generator itself has no end, and
+            # its long-cycle lookup runs off the table one step past schedule[-1]
+            if (max_steps_run is not None and done >= max_steps_run) or steps >= total_steps:
+                break
+            if long_ind != last_long:
+                bn_splits = model.update_bn_splits_long_cycle(LONG_CYCLE[long_ind])
+                optimizer.invalidate_graphs()   # captured graphs point at the split_bn buffers that were just re-created
+                lr_scale_fact = LONG_CYCLE[long_ind] if (last_long == -2 or long_ind == -1) else LONG_CYCLE_LR_SCALE[long_ind]
+                last_long = long_ind
+                for g in optimizer.param_groups:
+                    g['lr'] *= lr_scale_fact
+                    lr = g['lr']
+                if rank == 0:
+                    fr, cr = cbs.long_cycle_shapes(frames, 224)[long_ind]
+                    print_stats(long_ind, batch_size, (fr // gamma_tau, cr // 2, int(cr / 2 ** 0.5), cr), gamma_tau,
+                                bn_splits, lr)
+            if n_global % world != 0:
+                raise ValueError("step batch %d is not divisible by the world size %d" % (n_global, world))
+            B = n_global // world
+            if clip_size is not None:
+                H = max(8, H * clip_size // {'S': 160, 'M': 224, 'XL': 312, 'L': 312}[x3d_version])
+            inputs, labels = device_batch(B, T, H, 400, dev, gen)
+            loss, logits = optimizer.train_step(
+                inputs, labels, pre_step=lambda: lr_warmup(lr, steps - st_steps, warmup_steps, optimizer))
+            clips += n_global
+            if not optimizer.stepped:           # a micro-batch of an accumulated step (num_steps_per_update > 1)
+                continue
+            steps += 1
+            done += 1
+            lr_sched.step()
+            if done % log_every == 0 or done == 1:
+                tot_loss = float(loss)
+                preds = logits.argmax(1)
+                acc = float((preds == labels).float().mean())
+                if rank == 0:
+                    dt = time.time() - t0
+                    print(' step {} long {} shape ({},{},{}) loss {:.4f} acc {:.3f} lr {:.5f}  {:.1f} clips/s'.format(
+                        steps, long_ind, B, T, H, tot_loss, acc, optimizer.param_groups[0]['lr'], clips / dt), flush=True)
+            if val_every and done % val_every == 0:
+                Tv, Hv = frames // gamma_tau, crop_size
+                vb = []
+                for _ in range(val_batches):
+                    xv, yv = device_batch(val_batch_size * val_crops, Tv, Hv, 400, dev, gen)
+                    vb.append((xv.view(val_batch_size, val_crops, 3, Tv, Hv, Hv), yv.view(-1)[:val_batch_size]))
+                v_loss, v_acc, v_seen = validate(model, vb)
+                model.train(True)                                   # train...:199-200
+                if rank == 0:
+                    print(' val after step {}: Cls Loss: {:.4f} Acc: {:.4f} ({} videos)'.format(steps, v_loss, v_acc, v_seen),
+                          flush=True)
+            if save_every and steps % save_every == 0 and rank == 0:
+                _save_ckpt(model, optimizer, lr_sched, long_ind, save_model, steps)
+        if save_every and rank == 0 and steps >= total_steps and done > 0 and steps % save_every != 0:
+            _save_ckpt(model, optimizer, lr_sched, long_ind, save_model, steps)     # end of the schedule: final checkpoint
+    finally:
+        # runs on errors too: a rank that raised must not leave the others waiting inside a collective
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
     return steps, clips / max(time.time() - t0, 1e-9)
 
 

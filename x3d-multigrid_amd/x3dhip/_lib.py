@@ -67,6 +67,7 @@ SIGNATURES = {
     "x3d_bn_add_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "x3d_bn_relu_pool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "x3d_bn_relu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "x3d_grad_accumulate": (_I, [_P, _P, _Z, _F, _I, _P]),
     "x3d_sgd_fused": (_I, [_P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
 }
 

@@ -31,15 +31,25 @@ def _f(shape, like):
 
 
 _scratch = {}
+_scratch_retired = []
 
 
 def scratch(dev, nbytes):
-    """Grow-only per-device scratch for the finalize kernels (fp64 tile sums)."""
+    """Grow-only per-device scratch for the finalize kernels (fp64 tile sums).  Its raw pointer is baked into captured
+    hipGraphs, so a block that is outgrown is RETIRED, not freed: graphs captured earlier keep replaying into memory that
+    is still theirs (a few hundred KB per retired block; `release_retired_scratch` drops them once no graph is left)."""
     cur = _scratch.get(dev)
     if cur is None or cur.numel() < nbytes:
-        cur = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        if cur is not None:
+            _scratch_retired.append(cur)
+        cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
         _scratch[dev] = cur
     return cur
+
+
+def release_retired_scratch():
+    """Called by Trainer.invalidate_graphs() after every captured graph has been dropped."""
+    del _scratch_retired[:]
 
 
 def finalize_scratch(dev, N, C, Wd=0):
@@ -427,6 +437,11 @@ def bn_relu_pool_bwd(a5, c5, dpooled, g=None):
     segs = dpooled.shape[2] if dpooled.dim() == 3 else 1
     check(L.x3d_bn_relu_pool_bwd(ptr(a5), ptr(c5), ptr(dpooled), ptr(g), ptr(partial), N, C, P, segs, _lib.stream()))
     return g, partial
+
+
+def grad_accumulate(acc, g, scale, first):
+    _need_cuda(acc, g)
+    check(_lib.lib().x3d_grad_accumulate(ptr(acc), ptr(g), g.numel(), scale, 1 if first else 0, _lib.stream()))
 
 
 def sgd_fused(w, g, m, lr, momentum=0.9, weight_decay=5e-5, grad_scale=1.0, first=False):

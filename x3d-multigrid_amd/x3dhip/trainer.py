@@ -63,6 +63,9 @@ class GradReducer:
         self.flat_grad, self.buckets, self.world, self.pg = flat_grad, buckets, world_size, process_group
         self.stream = torch.cuda.Stream() if (world_size > 1 and flat_grad.is_cuda) else None
 
+    def buffers_like(self):
+        return list(self.buckets)
+
     def reduce(self):
         if self.world <= 1:
             return
@@ -103,9 +106,15 @@ class Trainer:
     owns the whole training step."""
 
     def __init__(self, model, lr, momentum=0.9, weight_decay=5e-5, process_group=None, world_size=1,
-                 use_graph=False):
+                 use_graph=False, num_steps_per_update=1):
         self.model = model
         self.fp = FlatParams(model)
+        # gradient accumulation (train_x3d_kinetics_multigrid.py:119,267-273): every train_step is one micro-batch with
+        # loss / num_steps_per_update; the parameters move on every num_steps_per_update-th call
+        self.num_steps_per_update = int(num_steps_per_update)
+        self._micro = 0
+        self.accum = torch.zeros_like(self.fp.grad) if self.num_steps_per_update > 1 else None
+        self.stepped = False
         self.param_groups = [dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay,
                                   nesterov=False, params=list(range(len(self.fp.params))))]
         self.pg = process_group
@@ -135,10 +144,10 @@ class Trainer:
     def _allreduce(self):
         self.reducer.reduce()
 
-    def _sgd(self):
+    def _sgd(self, grad=None):
         g = self.param_groups[0]
-        ops.sgd_fused(self.fp.flat, self.fp.grad, self.fp.mom, g['lr'], g['momentum'], g['weight_decay'],
-                      1.0 / self.world, first=self.first)
+        ops.sgd_fused(self.fp.flat, self.fp.grad if grad is None else grad, self.fp.mom, g['lr'], g['momentum'],
+                      g['weight_decay'], 1.0 / self.world, first=self.first)
         self.first = False
 
     # -- public -----------------------------------------------------------------------------
@@ -148,7 +157,12 @@ class Trainer:
 
     def train_step(self, x, y, pre_step=None):
         """forward + CE + backward (+ all-reduce) + SGD.  ``pre_step`` runs after backward and
-        before the parameter update (where the reference calls lr_warmup, train...:274)."""
+        before the parameter update (where the reference calls lr_warmup, train...:274).  With num_steps_per_update = K > 1
+        every call is one micro-batch: its gradient / K is added to the accumulation buffer, and only the K-th call
+        all-reduces, runs ``pre_step`` and updates the parameters (``self.stepped`` tells which kind of call it was)."""
+        if self.num_steps_per_update > 1:
+            return self._train_step_accum(x, y, pre_step)
+        self.stepped = True
         if self.use_graph and self._overlap():
             loss, logits = self._graphed_split(x, y)        # all-reduce issued inside, overlapped with the early layers
         else:
@@ -162,12 +176,52 @@ class Trainer:
         self._sgd()                          # outside any graph: lr / first-step flag are host values
         return loss, logits
 
+    MAX_GRAPHS = 6      # shapes of one long cycle: 2-3 (cycle_batch_sampler.py:98-111); each graph pins its activations
+
+    def _lookup(self, key):
+        """Graph cache: entries captured under an older split-BN layout point at split_bn buffers that
+        update_bn_splits_long_cycle has since re-created (x3d.py:298-303) -- they are dropped as soon as the version moves,
+        so a long-cycle switch releases their private pools (all activations of a step) instead of stranding them; the
+        cache is also bounded (least recently used first)."""
+        ver = self.model._bn_version
+        if getattr(self, "_graphs_version", ver) != ver and self._graphs:
+            self.invalidate_graphs()
+        self._graphs_version = ver
+        ent = self._graphs.pop(key, None)
+        if ent is not None:
+            self._graphs[key] = ent             # most recently used last
+        return ent
+
+    def _store(self, key, ent):
+        while len(self._graphs) >= self.MAX_GRAPHS:
+            self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = ent
+
+    def _train_step_accum(self, x, y, pre_step):
+        K = self.num_steps_per_update
+        loss, logits = self._graphed_fwd_bwd(x, y) if self.use_graph else self._fwd_bwd(x, y)
+        ops.grad_accumulate(self.accum, self.fp.grad, 1.0 / K, first=self._micro == 0)
+        self._micro += 1
+        self.stepped = self._micro == K
+        if self.stepped:
+            self._micro = 0
+            if self.world > 1:
+                # one exchange per optimizer step, on the accumulated gradient (no overlap with a backward pass here)
+                acc_reducer = GradReducer(self.accum, self.reducer.buffers_like(), self.world, self.pg) \
+                    if not hasattr(self, "_acc_reducer") else self._acc_reducer
+                self._acc_reducer = acc_reducer
+                acc_reducer.reduce()
+            if pre_step is not None:
+                pre_step()
+            self._sgd(self.accum)
+        return loss, logits
+
     def _graphed_fwd_bwd(self, x, y):
         key = (tuple(x.shape), self.model._bn_version, self.model.training)
-        ent = self._graphs.get(key)
+        ent = self._lookup(key)
         if ent is None:
             ent = self._capture(x, y)
-            self._graphs[key] = ent
+            self._store(key, ent)
         ent["x"].copy_(x)
         ent["y"].copy_(y)
         ent["fb"].replay()
@@ -228,10 +282,10 @@ class Trainer:
 
     def _graphed_split(self, x, y):
         key = ("split", tuple(x.shape), self.model._bn_version)
-        ent = self._graphs.get(key)
+        ent = self._lookup(key)
         if ent is None:
             ent = self._capture_split(x, y)
-            self._graphs[key] = ent
+            self._store(key, ent)
         ent["x"].copy_(x)
         ent["y"].copy_(y)
         ent["ga"].replay()
@@ -244,8 +298,12 @@ class Trainer:
 
     def invalidate_graphs(self):
         """Captured graphs hold pointers to split_bn buffers: drop them when those are re-created
-        (update_bn_splits_long_cycle) or when parameters are re-homed."""
+        (update_bn_splits_long_cycle) or when parameters are re-homed.  Called from the long-cycle switch
+        (train_x3d_kinetics_multigrid.run) and, as a safety net, by the cache lookup when the BN version moved."""
         self._graphs.clear()
+        ops.release_retired_scratch()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()         # hand the dropped graphs' private pools back to the device
 
     def _capture(self, x, y):
         sx, sy = x.clone(), y.clone()
