@@ -80,7 +80,7 @@ class KernelTimer:
 
         self._flush0 = flush0
         self.ops.DeferredGrads.flush = flush
-        for name in ("pw_fwd", "pw_bwd_data", "pw_bwd_data_res", "pw_bwd_weight", "dw333_fwd", "dw333_fwd_stats", "dw333_bwd", "stem133_fwd",
+        for name in ("pw_fwd", "pw_bwd_data", "pw_bwd_data_res", "pw_bwd_weight", "pw_bwd_fused", "dw333_fwd", "dw333_fwd_stats", "dw333_bwd", "stem133_fwd",
                      "stem133_bwd_weight", "dw5t_fwd", "dw5t_bwd", "bn_add_relu_fwd", "bn_stats_add_relu_fwd", "bn_add_relu_bwd",
                      "bn_relu_pool_fwd", "bn_relu_pool_bwd", "bn_fwd_finalize", "bn_bwd_finalize", "se_fwd",
                      "se_bn_bwd_finalize", "sgd_fused"):
@@ -100,7 +100,9 @@ class KernelTimer:
             r = fn(*a, **k)
             e1.record()
             shp = "x".join(map(str, a[0].shape)) if hasattr(a[0], "shape") else ""
-            if name.startswith("pw_"):
+            if name == "pw_bwd_fused":
+                shp += " w=" + "x".join(map(str, a[3][:2]))
+            elif name.startswith("pw_"):
                 shp += " w=" + "x".join(map(str, (a[1] if name == "pw_fwd" else a[3]).shape[:2])) if name != "pw_bwd_weight" else " w=" + "x".join(map(str, a[4][:2]))
             self.records.append((self.ALIAS.get(name, name), e0, e1, _alg_bytes(name, a, k, r), shp))
             return r
@@ -137,6 +139,8 @@ def _alg_bytes(name, a, k, r):
             return 4 * (xin + n(y))
         if name in ("pw_bwd_data", "pw_bwd_data_res"):
             return 4 * (n(a[0]) + n(r[0]))
+        if name == "pw_bwd_fused":                      # data-gradient pass + weight-gradient pass of SURVEY 8(d), one launch
+            return 4 * (n(a[0]) + n(r[0])) + 4 * (n(a[0]) + n(a[5]))
         if name == "pw_bwd_weight":
             stride = k.get("stride", 1)
             return 4 * (n(a[0]) + n(a[3]) // (stride * stride))

@@ -111,6 +111,28 @@ int x3d_pw_bwd_data_res(const float* g, const float* a, const float* cb, const f
                         float* out, int N, int Cin, int Cout, int T, int H, int W, const float* res_out,
                         const float* res_raw, const float* addend, int addend_stride, float* partial, void* stream);
 
+/* Fused backward (stages 1-2): the data gradient AND the weight-gradient partials of one pointwise convolution from ONE
+ * pass over g, a and x -- ConvolutionBackward's grad_input + grad_weight of conv1x1x1 (x3d.py:98-103 as Bottleneck.conv1 /
+ * conv3, :146,162) with the same fused BN backward in front and the same epilogues behind as the two separate entry
+ * points above (split-bf16 MFMA, 3 products, fp32 accumulate):
+ *   dY = cb0*g + cb1*a + cb2;   dIn[ci,p] = sum_co W[co,ci] dY[co,p] (+ addend);   dW[co,ci] += sum_p dY[co,p] X[ci,p]
+ *   X  = act(xpre0*x + xpre1) (xpre != NULL) or x -- the convolution's forward input
+ *   mode 0: out = dIn
+ *   mode 1: out = dIn * act'(xpre0*x + xpre1)                 partial {sum out, sum out*x}      (x3d_pw_bwd_data with pre)
+ *   mode 2: out = dIn where x > 0 else 0 (x = the producing block's output, xpre == NULL)
+ *                                                             partial {sum out, sum out*ex}     (x3d_pw_bwd_data_res)
+ * wpacked_t = the transposed pack of x3d_pw_pack (its split-bf16 planes are the data gradient's A operand).
+ * wpartial is float[x3d_pw_bwd_fused_groups(N,P)][Cout][Cin] (x3d_reduce_partials sums it); partial is
+ * float[N][Cin][x3d_pw_bwd_fused_tiles(P)][2].  x3d_pw_bwd_fused_ok tells whether (Cin, Cout, P) is in the kernel's set
+ * (dense, P % 4 == 0, both channel counts <= 128); other shapes use the separate entry points. */
+int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P);
+int x3d_pw_bwd_fused_groups(int N, int P);
+int x3d_pw_bwd_fused_tiles(int P);
+int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb, const float* wpacked_t, const float* x,
+                     const float* xpre, int xact, int mode, const float* ex, const float* addend, int addend_stride,
+                     float* dx, float* wpartial, float* partial, int N, int Cin, int Cout, int T, int H, int W,
+                     void* stream);
+
 /* Backward-weight: dW[co,ci] = sum_{n,p} dY[co,p] * in[ci,p] with dY and in formed as above
  * (strideHW 2: in is sampled at even (h,w) of x[N,Cin,T,H,W]; g,a are at output resolution).
  * wpartial is float[x3d_pw_wgrad_groups(...)][Cout][Cin]; x3d_reduce_partials sums it. */

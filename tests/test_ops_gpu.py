@@ -168,6 +168,79 @@ def test_pw_bwd_data_res(case):
             assert _rel(st[..., 1], (ref * res_raw).sum(dim=(2, 3, 4))) < 1e-4
 
 
+FUSED_CASES = [
+    # N, Cin, Cout, T, H, W, act of the conv's input prologue (mode 1) -- the stage 1-2 shapes of X3D-M plus tails
+    (2, 24, 54, 4, 16, 16, 1),      # conv1 of stage 1 (64 x 32 tile)
+    (2, 54, 24, 4, 16, 16, 2),      # conv3 of stage 1 (32 x 64 tile)
+    (3, 48, 108, 2, 20, 20, 1),     # conv1 of stage 2 (128 x 64), P = 800: last chunk half empty
+    (2, 108, 48, 2, 14, 14, 2),     # conv3 of stage 2 (64 x 128), P = 392: tail of 8 voxels
+    (2, 24, 108, 4, 12, 12, 1),     # layer2.0 conv1 (128 x 32)
+    (2, 40, 60, 2, 10, 10, 2),      # padded to (64, 64)
+    (9, 24, 54, 2, 8, 8, 1),        # more chunks than one round of a small grid (X3D_FB_GRID is 512: 18 chunks)
+    (1, 60, 20, 1, 2, 2, 0),        # P = 4: a single partial chunk
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_pw_bwd_fused(case):
+    """x3d_pw_bwd_fused (data gradient + weight gradient in one pass, stages 1-2) against the fp64 evaluation of the
+    same fused op, in its three epilogue modes, dense and stride-2 addend."""
+    from x3dhip import ops
+    dev = _dev()
+    N, Ci, Co, T, H, W, act = case
+    assert ops.pw_bwd_fused_ok(Ci, Co, T * H * W)
+    x = _g(N, Ci, T, H, W, seed=1)
+    w = _g(Co, Ci, seed=2) / np.sqrt(Ci)
+    pre = torch.stack([1 + 0.2 * _g(N, Ci, seed=3), 0.3 * _g(N, Ci, seed=4)], -1)
+    g = _g(N, Co, T, H, W, seed=5)
+    a = _g(N, Co, T, H, W, seed=6)
+    cb = torch.stack([1 + 0.1 * _g(N, Co, seed=7), 0.1 * _g(N, Co, seed=8), 0.05 * _g(N, Co, seed=9)], -1)
+    dY = cb[..., 0, None, None, None] * g + cb[..., 1, None, None, None] * a + cb[..., 2, None, None, None]
+    din = F.conv_transpose3d(dY, w.view(Co, Ci, 1, 1, 1))
+    addend = _g(N, Ci, T, H, W, seed=10)
+    H2, W2 = xo.out_hw(H, 2), xo.out_hw(W, 2)
+    add2 = _g(N, Ci, T, H2, W2, seed=11)
+    full = torch.zeros(N, Ci, T, H, W, dtype=torch.float64)
+    full[:, :, :, ::2, ::2] = add2
+    to = lambda t: None if t is None else t.float().contiguous().to(dev)
+    wpt = ops.pw_pack(to(w), transposed=True)
+    dwr = lambda xin: torch.einsum("nopqr,nipqr->oi", dY, xin)
+
+    # mode 0: plain (+ addend); the conv's input is the materialised x
+    for add, astride, ref in ((None, 1, din), (addend, 1, din + addend), (add2, 2, din + full)):
+        dx, partial, dw = ops.pw_bwd_fused(to(g), to(a), to(cb), (Co, Ci), wpt, to(x), mode=0, addend=to(add),
+                                           addend_stride=astride)
+        assert partial is None
+        assert _rel(dx, ref) < TOL
+        assert _rel(dw, dwr(x)) < TOL
+    # mode 1: activation backward of the conv's input (x raw, pre): conv3 (Swish), layer1.0 conv1 (ReLU of the stem)
+    if act:
+        sx = pre[..., 0, None, None, None] * x + pre[..., 1, None, None, None]
+        for add, astride, base in ((None, 1, din), (add2, 2, din + full)):
+            ref = base * _dact(sx, act)
+            dx, partial, dw = ops.pw_bwd_fused(to(g), to(a), to(cb), (Co, Ci), wpt, to(x), xpre=to(pre), xact=act, mode=1,
+                                               addend=to(add), addend_stride=astride)
+            assert _rel(dx, ref) < TOL
+            assert _rel(dw, dwr(_act(sx, act))) < TOL
+            st = partial.double().sum(2).cpu()
+            assert _rel(st[..., 0], ref.sum(dim=(2, 3, 4))) < 1e-4
+            assert _rel(st[..., 1], (ref * x).sum(dim=(2, 3, 4))) < 1e-4
+    # mode 2: residual-add + ReLU backward of the producing block (x = its output, ex = its raw conv3 output)
+    xo_ = torch.relu(x)
+    ex = _g(N, Ci, T, H, W, seed=13)
+    mask = (xo_ > 0).double()
+    for add, astride, base in ((addend, 1, din + addend), (add2, 2, din + full)):
+        ref = base * mask
+        dx, partial, dw = ops.pw_bwd_fused(to(g), to(a), to(cb), (Co, Ci), wpt, to(xo_), mode=2, ex=to(ex), addend=to(add),
+                                           addend_stride=astride)
+        assert _rel(dx, ref) < TOL
+        assert bool((dx.cpu()[mask == 0] == 0).all())
+        assert _rel(dw, dwr(xo_)) < TOL
+        st = partial.double().sum(2).cpu()
+        assert _rel(st[..., 0], ref.sum(dim=(2, 3, 4))) < 1e-4
+        assert _rel(st[..., 1], (ref * ex).sum(dim=(2, 3, 4))) < 1e-4
+
+
 DW_CASES = [
     # N, C, T, H, W, stride
     (2, 6, 4, 14, 14, 1),

@@ -126,6 +126,18 @@ _NO_DW_STATS = os.environ.get("X3D_NO_DW_STATS", "0") == "1"
 _DW_BWD_STATS = os.environ.get("X3D_DW_BWD_STATS", "1") == "1"
 _NO_RES_FUSE = os.environ.get("X3D_NO_RES_FUSE", "0") == "1"
 _NO_BATCH_REDUCE = os.environ.get("X3D_NO_BATCH_REDUCE", "0") == "1"
+_NO_FUSED_BWD = os.environ.get("X3D_NO_FUSED_BWD", "0") == "1"
+
+
+def _fused_bwd(grads, g, x):
+    """Stages 1-2: data gradient and weight gradient of a pointwise conv from one pass (ops.pw_bwd_fused)."""
+    if _NO_FUSED_BWD or grads.side is not None or os.environ.get("X3D_EXP_SKIP_WGRAD") == "1":
+        return False
+    if os.environ.get("X3D_DGRAD_F32") or os.environ.get("X3D_WGRAD_F32"):      # exact-fp32 A/B switches: separate kernels
+        return False
+    if tuple(x.shape[2:]) != tuple(g.shape[2:]):
+        return False
+    return ops.pw_bwd_fused_ok(x.shape[1], g.shape[1], g[0, 0].numel())
 
 
 def _bn_train(partial, bn, S, count, want_nsum=False):
@@ -415,10 +427,16 @@ def _block_backward(rec, dout, grads, below=None):
         g3, p3, pd = ops.bn_add_relu_bwd(dout, rec["out"], a3, ad)
     cb3 = _bn_bwd(grads, p3, S, P2, blk.bn3, rec["s3"])
 
-    # conv3: weight gradient, then data gradient fused with the swish backward
-    _wgrad(grads, blk.conv3.weight, g3, a3, cb3, a2, pre=rec["c2e"], pre_act=ACT_SWISH)
-    ds, ps = ops.pw_bwd_data(g3, a3, cb3, _w2d(blk.conv3.weight), x=a2, pre=rec["c2e"], pre_act=ACT_SWISH,
-                             wpt=rec["w3t"])
+    # conv3: weight gradient, then data gradient fused with the swish backward (one pass at stages 1-2)
+    if _fused_bwd(grads, g3, a2):
+        w3 = blk.conv3.weight
+        ds, ps, dw3 = ops.pw_bwd_fused(g3, a3, cb3, w3.shape, rec["w3t"], a2, xpre=rec["c2e"], xact=ACT_SWISH, mode=1,
+                                       dw_out=grads.out(w3), defer=grads.deferred)
+        grads.put(w3, dw3)
+    else:
+        _wgrad(grads, blk.conv3.weight, g3, a3, cb3, a2, pre=rec["c2e"], pre_act=ACT_SWISH)
+        ds, ps = ops.pw_bwd_data(g3, a3, cb3, _w2d(blk.conv3.weight), x=a2, pre=rec["c2e"], pre_act=ACT_SWISH,
+                                 wpt=rec["w3t"])
     if blk.has_se:
         se = rec["se"]
         outs = None
@@ -458,7 +476,9 @@ def _block_backward(rec, dout, grads, below=None):
     cb1 = _bn_bwd(grads, p1, S, P1, blk.bn1, rec["s1"])
 
     # conv1 (+ downsample branch)
-    _wgrad(grads, blk.conv1.weight, g1, a1, cb1, x_raw, pre=x_coef, pre_act=pre_act)
+    fuse1 = _fused_bwd(grads, g1, x_raw)
+    if not fuse1:
+        _wgrad(grads, blk.conv1.weight, g1, a1, cb1, x_raw, pre=x_coef, pre_act=pre_act)
     if blk.downsample is not None:
         dsc, dsb = blk.downsample[0], blk.downsample[1]
         cbd = _bn_bwd(grads, pd, S, P2, dsb, rec["sd"])
@@ -467,6 +487,18 @@ def _block_backward(rec, dout, grads, below=None):
         astride = blk.stride
     else:
         addend, astride = g3, 1
+    if fuse1:
+        w1 = blk.conv1.weight
+        if _res_fusable(below):            # x_raw IS below["out"]: the mask of the producer's ReLU and the conv's input
+            mode, kw = 2, dict(ex=below["a3"])
+        elif x_coef is not None:           # lazily normalised input (layer1.0: the stem's BN + ReLU)
+            mode, kw = 1, dict(xpre=x_coef, xact=pre_act)
+        else:
+            mode, kw = 0, {}
+        dprev, pprev, dw1 = ops.pw_bwd_fused(g1, a1, cb1, w1.shape, rec["w1t"], x_raw, mode=mode, addend=addend,
+                                             addend_stride=astride, dw_out=grads.out(w1), defer=grads.deferred, **kw)
+        grads.put(w1, dw1)
+        return ((dprev, pprev), None) if mode == 2 else (dprev, pprev)
     if _res_fusable(below):
         return ops.pw_bwd_data_res(g1, a1, cb1, _w2d(blk.conv1.weight), below["out"], below["a3"], addend=addend,
                                    addend_stride=astride, wpt=rec["w1t"]), None

@@ -193,6 +193,38 @@ def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, ou
     return dw.view(w_shape)
 
 
+def pw_bwd_fused_ok(Cin, Cout, P):
+    return bool(_lib.lib().x3d_pw_bwd_fused_ok(Cin, Cout, P))
+
+
+def pw_bwd_fused(g, a, cb, w_shape, wpt, x, xpre=None, xact=ACT_NONE, mode=0, ex=None, addend=None, addend_stride=1,
+                 dw_out=None, defer=None):
+    """Data gradient + weight gradient of a pointwise conv in one pass (x3d_pw_bwd_fused).  mode 0 plain, 1 activation
+    backward (x raw, xpre), 2 residual-add + ReLU backward of the producing block (x = its output, ex = its raw conv3
+    output).  Returns (dx, partial or None, dW); the group sum of the dW partials goes to `defer` (DeferredGrads) when
+    given, else it runs here."""
+    _need_cuda(g, a, cb, wpt, x, xpre, ex, addend)
+    L = _lib.lib()
+    N, Cout, T, H, W = g.shape
+    Cin = x.shape[1]
+    P = T * H * W
+    if tuple(x.shape) != (N, Cin, T, H, W):
+        raise ValueError("pw_bwd_fused: x must be [N, Cin, T, H, W] of the gradient's geometry (dense convolution)")
+    groups = L.x3d_pw_bwd_fused_groups(N, P)
+    dx = _f((N, Cin, T, H, W), g)
+    wpartial = _f((groups, Cout * Cin), g)
+    partial = _f((N, Cin, L.x3d_pw_bwd_fused_tiles(P), 2), g) if mode != 0 else None
+    check(L.x3d_pw_bwd_fused(ptr(g), ptr(a), ptr(cb), ptr(wpt), ptr(x), ptr(xpre), xact, mode, ptr(ex), ptr(addend),
+                             addend_stride, ptr(dx), ptr(wpartial), ptr(partial), N, Cin, Cout, T, H, W, _lib.stream()))
+    o = dw_out if dw_out is not None else _f((Cout * Cin,), g)
+    if defer is not None:
+        defer.reduces.append((wpartial, o))
+        defer.keep.append((wpartial,))
+    else:
+        reduce_partials(wpartial, Cout * Cin, out=o)
+    return dx, partial, o.view(w_shape)
+
+
 # ----------------------------------------------------------------------------- channelwise
 def dw333_fwd(x, w, stride=1, pre=None, pre_act=ACT_RELU, want_stats=True, out=None, partial=None):
     _need_cuda(x, w, pre)
