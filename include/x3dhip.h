@@ -123,9 +123,9 @@ int x3d_pw_bwd_data_res(const float* g, const float* a, const float* cb, const f
  *                                                             partial {sum out, sum out*ex}     (x3d_pw_bwd_data_res)
  * wpacked_t = the transposed pack of x3d_pw_pack (its split-bf16 planes are the data gradient's A operand).
  * wpartial is float[x3d_pw_bwd_fused_groups(N,P)][Cout][Cin] (x3d_reduce_partials sums it); partial is
- * float[N][Cin][x3d_pw_bwd_fused_tiles(P)][2].  x3d_pw_bwd_fused_ok tells whether (Cin, Cout, P) is in the kernel's set
+ * float[N][Cin][x3d_pw_bwd_fused_tiles(P)][2].  x3d_pw_bwd_fused_ok tells whether (Cin, Cout, P, mode, addend) is in the kernel's set
  * (dense, P % 4 == 0, both channel counts <= 128); other shapes use the separate entry points. */
-int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P);
+int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P, int mode, int has_addend);
 int x3d_pw_bwd_fused_groups(int N, int P);
 int x3d_pw_bwd_fused_tiles(int P);
 int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb, const float* wpacked_t, const float* x,

@@ -45,27 +45,50 @@ struct FbArgs {
 
 constexpr int F_LD = 72;           // bf16 elements per LDS row (144 B: conflict-free b128 row reads)
 constexpr int F_PT = 64;           // voxels per chunk
+constexpr int F_RL = 68;           // floats per row of the raw fp32 LDS tiles
+
+// load from a wave-uniform base (SGPR pair) + 32-bit byte offset (one VGPR): `global_load ... v_off, s[base]`
+template <typename T>
+__device__ __forceinline__ T ldg_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 __device__ __forceinline__ bf16x8 cat8(bf16x4 lo4, bf16x4 hi4) {
     return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // CO: dY channels padded to a multiple of 32 (<= 128), CI: input channels padded to a multiple of 32 (<= 128).
-template <int CO, int CI, int EPI>
-__global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_kernel(const FbArgs A) {
-    constexpr int ND = CO / 16, NX = CI / 16;              // staged float4 slots per thread (dY rows, X rows)
+// NWV waves per workgroup (4 or 8); OCC = waves per SIMD the register budget is sized for.
+// Occupancy is the latency hiding here: a workgroup runs its chunk as fetch -> stage -> MFMA -> epilogue without a register
+// prefetch across chunks (that version needed 180-256 registers and ran at 1-2 waves per SIMD, 2x off the HBM time);
+// the global round trips of one workgroup are covered by the other 3-4 resident on the CU.
+template <int CO, int CI, int EPI, bool ADD, int NWV, int OCC>
+__global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArgs A) {
+    constexpr int NT = 64 * NWV;                           // threads
+    constexpr int RP = NT / 16;                            // rows staged per pass (16 lanes x float4 = one 64-voxel row)
+    constexpr int ND = (CO + RP - 1) / RP, NX = (CI + RP - 1) / RP;   // staged float4 slots per thread (dY rows, X rows)
     constexpr int KS = CO / 32;                            // k steps (32 channels) of the data gradient
-    constexpr int U = CI / 32;                             // data-gradient units per wave: ci tiles (wave >> 1) + 2 j
-    constexpr bool BYCO = (CO / 16) >= 4;                  // weight-gradient tiles: waves split the co tiles, or the ci tiles
-    constexpr int MW = BYCO ? CO / 64 : CO / 16;
-    constexpr int NW = BYCO ? CI / 16 : CI / 64;
-    static_assert(CO % 32 == 0 && CI % 32 == 0 && (BYCO || CI % 64 == 0), "tile shape");
+    constexpr int MP = NWV / 2;                            // data-gradient: waves per voxel half
+    constexpr int U = (CI / 16 + MP - 1) / MP;             // units per wave: ci tiles (wave >> 1) + MP j
+    // weight gradient: WCO waves along the co tiles, WCI along the ci tiles
+    constexpr int WCO = (CO / 16) < NWV ? (CO / 16) : NWV;
+    constexpr int WCI = NWV / WCO;
+    constexpr int MW = CO / 16 / WCO, NW = CI / 16 / WCI;
+    static_assert(CO % 32 == 0 && CI % 32 == 0, "tile shape");
+    static_assert(WCO * WCI == NWV && MW * WCO * 16 == CO && NW * WCI * 16 == CI, "weight-gradient tiling");
 
     __shared__ __attribute__((aligned(16))) __bf16 Dh[CO * F_LD];
     __shared__ __attribute__((aligned(16))) __bf16 Dlo[CO * F_LD];
     __shared__ __attribute__((aligned(16))) __bf16 Xh[CI * F_LD];
     __shared__ __attribute__((aligned(16))) __bf16 Xlo[CI * F_LD];
-    __shared__ float red[(EPI == FE_PLAIN) ? 4 : 4 * U * 16 * 2];
+    __shared__ float red[(EPI == FE_PLAIN) ? 4 : NWV * U * 16 * 2];
+    __shared__ __attribute__((aligned(16))) __bf16 Wl[(CI / 16) * KS * 2 * 64 * 8];
+    // epilogue operands of the chunk, staged raw (fp32, natural voxel order) with the same coalesced row loads as the
+    // GEMM operands: x (activation backward / ReLU mask / statistics), ex, dense addend
+    __shared__ __attribute__((aligned(16))) float Xr[(EPI != FE_PLAIN) ? CI * F_RL : 4];
+    __shared__ __attribute__((aligned(16))) float Er[(EPI == FE_RESBWD) ? CI * F_RL : 4];
+    __shared__ __attribute__((aligned(16))) float Ar[ADD ? CI * F_RL : 4];
+    __shared__ float2 Cf[(EPI == FE_ACTBWD) ? CI : 1];     // per-row BN coefficients of the chunk's sample (activation backward)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,39 +99,11 @@ __global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_k
     const int total = A.N * cps;
     const int G = gridDim.x;
 
-    // ---- staging roles: rows row0 + 16 i, voxels c4 .. c4 + 3 of the chunk (256 B contiguous per row and 16 lanes)
+    // ---- staging roles: rows row0 + RP i, voxels c4 .. c4 + 3 of the chunk (256 B contiguous per row and 16 lanes)
     const int c4 = (tid & 15) * 4;
     const int row0 = tid >> 4;
     // LDS column of voxel c4 (even) / c4 + 1 (odd); c4 + 2 / c4 + 3 follow at + 1
     const int colE = (c4 & 32) + ((c4 & 31) >> 1), colO = colE + 16;
-
-    float4 rg[ND], ra[ND], rx[NX];
-    float k0[ND], k1[ND], k2[ND], sc[NX], sh[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
-
-    auto fetch = [&](int c) {
-        const int n = c / cps, pt = (c - n * cps) * F_PT;
-        const int pc = min(pt + c4, P - 4);
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const int co = min(row0 + 16 * i, Co - 1);
-            const size_t base = ((size_t)n * Co + co) * (size_t)P + pc;
-            rg[i] = *reinterpret_cast<const float4*>(A.g + base);
-            ra[i] = *reinterpret_cast<const float4*>(A.a + base);
-            const float* cb = A.cb + ((size_t)n * Co + co) * 3;
-            k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int ci = min(row0 + 16 * i, Ci - 1);
-            rx[i] = *reinterpret_cast<const float4*>(A.x + ((size_t)n * Ci + ci) * (size_t)P + pc);
-            if (A.xpre != nullptr) {
-                const float2 p2 = *reinterpret_cast<const float2*>(A.xpre + ((size_t)n * Ci + ci) * 2);
-                sc[i] = p2.x; sh[i] = p2.y;
-            }
-        }
-    };
 
     auto put = [&](__bf16* plane_h, __bf16* plane_l, int row, const float (&v)[4]) {
         bf16x2 he, ho, le, lo;
@@ -124,29 +119,102 @@ __global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_k
         *reinterpret_cast<bf16x2*>(&plane_l[row * F_LD + colO]) = lo;
     };
 
-    auto store = [&](int c) {
-        const int n = c / cps, pt = (c - n * cps) * F_PT;
+    // global -> registers (fetch, issued one chunk ahead) -> (BN-backward combine | forward prologue) -> split-bf16 LDS images
+    float4 rg[ND], ra[ND], rx[NX], rex[(EPI == FE_RESBWD) ? NX : 1], radd[ADD ? NX : 1];
+    float k0[ND], k1[ND], k2[ND], sc[NX], sh[NX];
+    const bool add_dense = ADD && A.addend_stride == 1;
+    unsigned add_even = 0;                                  // stride-2 addend: bit e = voxel e of this thread's four lands on the coarse grid
+    auto fetch = [&](int n, int pt) {
+        const int pc = min(pt + c4, P - 4);
+        // stride-2 addend (the downsample branch's compact gradient [T][Ho][Wo], first block of a stage): its value for
+        // voxel (t, h, w) exists where h and w are even; the offsets depend on the voxel only, so they are walked once
+        unsigned aoff[4] = {0, 0, 0, 0};
+        if (ADD && !add_dense) {
+            const int hw = A.H * A.W;
+            int t = pc / hw, rem = pc - t * hw;
+            int h = rem / A.W, w = rem - h * A.W;
+            add_even = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool even = !(h & 1) && !(w & 1);
+                add_even |= even ? (1u << e) : 0u;
+                aoff[e] = even ? (unsigned)((t * A.Ho + (h >> 1)) * A.Wo + (w >> 1)) : 0u;
+                if (++w == A.W) { w = 0; if (++h == A.H) { h = 0; ++t; } }
+            }
+        }
+        // per-sample bases are wave uniform (SGPRs); a row of one sample is < 4 GB away: 32-bit byte offsets
+        const float* gs = A.g + (size_t)n * Co * (size_t)P;
+        const float* as = A.a + (size_t)n * Co * (size_t)P;
+        const float* xs = A.x + (size_t)n * Ci * (size_t)P;
+        const float* cbs = A.cb + (size_t)n * Co * 3;
+        const float* xps = A.xpre != nullptr ? A.xpre + (size_t)n * Ci * 2 : nullptr;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const unsigned co = (unsigned)min(row0 + RP * i, Co - 1);
+            const unsigned off = (co * (unsigned)P + (unsigned)pc) * 4u;
+            rg[i] = ldg_off<float4>(gs, off);
+            ra[i] = ldg_off<float4>(as, off);
+            k0[i] = ldg_off<float>(cbs, co * 12u); k1[i] = ldg_off<float>(cbs, co * 12u + 4u); k2[i] = ldg_off<float>(cbs, co * 12u + 8u);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const unsigned ci = (unsigned)min(row0 + RP * i, Ci - 1);
+            const unsigned xoff = (ci * (unsigned)P + (unsigned)pc) * 4u;
+            rx[i] = ldg_off<float4>(xs, xoff);
+            if (EPI == FE_RESBWD) rex[i] = ldg_off<float4>(A.ex + (size_t)n * Ci * (size_t)P, xoff);
+            if (ADD) {
+                if (add_dense) {
+                    radd[i] = ldg_off<float4>(A.addend + (size_t)n * Ci * (size_t)P, xoff);
+                } else {
+                    const unsigned addP = (unsigned)(A.T * A.Ho * A.Wo);
+                    const float* ads = A.addend + (size_t)n * Ci * (size_t)addP;
+                    const unsigned ab = ci * addP;
+                    radd[i] = make_float4(ldg_off<float>(ads, (ab + aoff[0]) * 4u), ldg_off<float>(ads, (ab + aoff[1]) * 4u),
+                                          ldg_off<float>(ads, (ab + aoff[2]) * 4u), ldg_off<float>(ads, (ab + aoff[3]) * 4u));
+                }
+            }
+            sc[i] = 1.f; sh[i] = 0.f;
+            if (xps != nullptr) {
+                const float2 p2 = ldg_off<float2>(xps, ci * 8u);
+                sc[i] = p2.x; sh[i] = p2.y;
+            }
+        }
+    };
+    auto store = [&](int pt) {
         const bool pvv = pt + c4 < P;                       // P % 4 == 0: all four voxels or none
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const bool ok = pvv && (row0 + 16 * i < Co);
+            const bool ok = pvv && (row0 + RP * i < Co);
             const float gv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w}, av[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
-            put(Dh, Dlo, row0 + 16 * i, v);
+            if (CO % RP == 0 || row0 + RP * i < CO) put(Dh, Dlo, row0 + RP * i, v);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const bool ok = pvv && (row0 + 16 * i < Ci);
+            const bool ok = pvv && (row0 + RP * i < Ci);
             float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+            if (CI % RP == 0 || row0 + RP * i < CI) {
+                if (EPI != FE_PLAIN) *reinterpret_cast<float4*>(&Xr[(row0 + RP * i) * F_RL + c4]) = rx[i];
+                if (EPI == FE_ACTBWD && c4 == 0) Cf[row0 + RP * i] = make_float2(sc[i], sh[i]);
+                if (EPI == FE_RESBWD) *reinterpret_cast<float4*>(&Er[(row0 + RP * i) * F_RL + c4]) = rex[i];
+                if (ADD) {
+                    float4 av4 = radd[i];
+                    if (!add_dense) {
+                        av4.x = (add_even & 1u) ? av4.x : 0.f; av4.y = (add_even & 2u) ? av4.y : 0.f;
+                        av4.z = (add_even & 4u) ? av4.z : 0.f; av4.w = (add_even & 8u) ? av4.w : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(&Ar[(row0 + RP * i) * F_RL + c4]) = av4;
+                }
+            }
             if (A.xpre != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(sc[i], v[e], sh[i]), A.xact);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-            put(Xh, Xlo, row0 + 16 * i, v);
+            if (CI % RP == 0 || row0 + RP * i < CI) put(Xh, Xlo, row0 + RP * i, v);
         }
     };
 
@@ -156,12 +224,12 @@ __global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_k
     for (int i = 0; i < MW; ++i)
 #pragma unroll
         for (int j = 0; j < NW; ++j) wacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int wco0 = BYCO ? MW * wave : 0, wci0 = BYCO ? 0 : NW * wave;          // first co / ci tile of this wave
+    const int wco0 = MW * (wave % WCO), wci0 = NW * (wave / WCO);          // first co / ci tile of this wave
 
     auto compute_w = [&]() {
 #pragma unroll
         for (int s = 0; s < F_PT / 32; ++s) {
-            bf16x8 ah[MW], al[MW], bh[NW], bl[NW];
+            bf16x8 ah[MW], al[MW];
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
                 const int off = ((wco0 + i) * 16 + r) * F_LD + s * 32 + 8 * q;
@@ -171,32 +239,39 @@ __global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_k
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const int off = ((wci0 + j) * 16 + r) * F_LD + s * 32 + 8 * q;
-                bh[j] = *reinterpret_cast<const bf16x8*>(&Xh[off]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
-            }
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Xh[off]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
 #pragma unroll
-            for (int i = 0; i < MW; ++i)
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], wacc[i][j], 0, 0, 0);
-                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], wacc[i][j], 0, 0, 0);
-                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], wacc[i][j], 0, 0, 0);
+                for (int i = 0; i < MW; ++i) {
+                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, wacc[i][j], 0, 0, 0);
+                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, wacc[i][j], 0, 0, 0);
+                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, wacc[i][j], 0, 0, 0);
                 }
+            }
         }
     };
 
-    // ---- data gradient: units (ci tile (wave >> 1) + 2 j, 32-voxel half wave & 1), channel index on K
+    // ---- data gradient: units (ci tile (wave >> 1) + MP j, 32-voxel half wave & 1), channel index on K
     const int mtiles = (Ci + 15) / 16, kg16 = (Co + 15) / 16, kg32 = (Co + 31) / 32;
     const __bf16* wqh = reinterpret_cast<const __bf16*>(A.wpt + (size_t)mtiles * kg16 * 256);
     const __bf16* wql = wqh + (size_t)mtiles * kg32 * 512;
     f32x4 dacc[U][2];
+    // A operand (transposed weights, pre-split, MFMA fragment order): chunk invariant -- copied once into LDS
+    // ([ci tile][k step][plane][lane][8]), one ds_read_b128 per fragment and chunk instead of 8 registers per fragment
+    for (int i = tid; i < (CI / 16) * KS * 2 * 64; i += NT) {
+        const int ln = i & 63, pl = (i >> 6) & 1, rest = i >> 7;
+        const int s = rest % KS, mt = rest / KS;
+        const int mtc = min(mt, mtiles - 1), sc_ = min(s, kg32 - 1);          // clamped: never stored / zero dY rows
+        const size_t off = (((size_t)mtc * kg32 + sc_) * 64 + ln) * 8;
+        *reinterpret_cast<bf16x8*>(&Wl[(size_t)i * 8]) = *reinterpret_cast<const bf16x8*>((pl ? wql : wqh) + off);
+    }
 
     // transposed fragment of the dY image: lane (col i = lane & 15, k group g = lane >> 4) gets dY[32 s + 8 g + 0..7][col]
     // for the 16 columns starting at col0; lane 4 qq + pp of a 16-lane group supplies the address of row qq, columns 4 pp ..
-    const int tr_row = 8 * q + (r >> 2), tr_col = 4 * (r & 3);
-    auto tr_frag = [&](const __bf16* plane, int s, int col0) -> bf16x8 {
+    const int tr_off = (8 * q + (r >> 2)) * F_LD + 4 * (r & 3) + 32 * half;
+    auto tr_frag = [&](const __bf16* plane, int s, int h2) -> bf16x8 {
         typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-        const __bf16* p0 = plane + (32 * s + tr_row) * F_LD + col0 + tr_col;
+        const __bf16* p0 = plane + 32 * s * F_LD + tr_off + 16 * h2;
         const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
         const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * F_LD));
         return cat8(v0, v1);
@@ -210,16 +285,14 @@ __global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_k
             bf16x8 bh[2], bl[2];
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                bh[h2] = tr_frag(Dh, s, 32 * half + 16 * h2);
-                bl[h2] = tr_frag(Dlo, s, 32 * half + 16 * h2);
+                bh[h2] = tr_frag(Dh, s, h2);
+                bl[h2] = tr_frag(Dlo, s, h2);
             }
-            const int sc_ = min(s, kg32 - 1);               // clamped: the dY rows of a k step past Co are zero
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                const int mt = min(mpar + 2 * j, mtiles - 1);                  // clamped: duplicates are never stored
-                const size_t off = (((size_t)mt * kg32 + sc_) * 64 + lane) * 8;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wqh + off);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wql + off);
+                const int mtl_ = min(mpar + MP * j, CI / 16 - 1);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * 2 + 0) * 64 + lane) * 8]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * 2 + 1) * 64 + lane) * 8]);
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[h2], dacc[j][h2], 0, 0, 0);
@@ -230,80 +303,46 @@ __global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_k
         }
     };
 
-    const bool has_add = A.addend != nullptr;
-    const bool add_s2 = has_add && A.addend_stride == 2;
-    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
-
-    // epilogue of one chunk: lane owns rows 4 q + e of each unit and voxels 32 half + 2 r, + 1
-    auto epilogue = [&](int c) {
-        const int n = c / cps, tile = c - n * cps;
-        const int pl = tile * F_PT + 32 * half + 2 * r;
+    // epilogue of one chunk: lane owns rows 4 q + e of each unit and voxels 32 half + 2 r, + 1; operands from the raw LDS
+    // tiles (the chunk's tail columns hold clamped duplicates: masked by pv)
+    auto epilogue = [&](int n, int tile) {
+        const int vl = 32 * half + 2 * r;                     // voxel within the chunk
+        const int pl = tile * F_PT + vl;
         const bool pv = pl < P;                               // P even: both voxels or none
-        const int pc = pv ? pl : 0;
-        int aoff[2] = {pc, pc + 1};
-        bool av[2] = {has_add && pv, has_add && pv};
-        if (add_s2) {
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2) {
-                const int p = pc + j2;
-                const int hw = A.H * A.W;
-                const int t = p / hw, rem = p - t * hw;
-                const int h = rem / A.W, w = rem - h * A.W;
-                const bool even = !(h & 1) && !(w & 1);
-                av[j2] = av[j2] && even;
-                aoff[j2] = even ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0;
-            }
-        }
+        float* dxs = A.dx + (size_t)n * Ci * (size_t)P;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int lt = mpar + 2 * j;
-            // phase 1: the four rows' reads, branch-free from clamped addresses (the x rows were fetched by this
-            // workgroup for the staging of this very chunk: L2 hits)
-            float xv[4][2], ev[4][2], adv[4][2], esc[4], esh[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ml = lt * 16 + 4 * q + e;
-                const size_t mrow = (size_t)n * Ci + (ml < Ci ? ml : 0);
-                if (EPI == FE_ACTBWD) {
-                    const float2 c2 = *reinterpret_cast<const float2*>(A.xpre + mrow * 2);
-                    esc[e] = c2.x; esh[e] = c2.y;
-                }
-                if (EPI != FE_PLAIN) {
-                    const float2 t2 = *reinterpret_cast<const float2*>(A.x + mrow * (size_t)P + pc);
-                    xv[e][0] = t2.x; xv[e][1] = t2.y;
-                }
-                if (EPI == FE_RESBWD) {
-                    const float2 t2 = *reinterpret_cast<const float2*>(A.ex + mrow * (size_t)P + pc);
-                    ev[e][0] = t2.x; ev[e][1] = t2.y;
-                }
-                if (has_add) {
-                    const float* pa = A.addend + mrow * (size_t)addP;
-                    if (!add_s2) {
-                        const float2 t2 = *reinterpret_cast<const float2*>(pa + pc);
-                        adv[e][0] = t2.x; adv[e][1] = t2.y;
-                    } else {
-                        adv[e][0] = pa[aoff[0]]; adv[e][1] = pa[aoff[1]];
-                    }
-                }
-            }
-            // phase 2
+            const int lt = mpar + MP * j;
+            if (lt * 16 >= CI) continue;                      // wave-uniform: this unit does not exist (16-wave variants)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = lt * 16 + 4 * q + e;
                 const bool mv = ml < Ci;
                 float v[2] = {dacc[j][0][e], dacc[j][1][e]};
                 float s1 = 0.f, s2 = 0.f;
-                if (has_add) { v[0] += av[0] ? adv[e][0] : 0.f; v[1] += av[1] ? adv[e][1] : 0.f; }
+                float esc = 1.f, esh = 0.f;
+                if (EPI == FE_ACTBWD) {                       // no global load here: it would queue behind the prefetch (vmcnt is in order)
+                    const float2 c2 = Cf[ml];
+                    esc = c2.x; esh = c2.y;
+                }
+                if (ADD) {
+                    const float2 a2 = *reinterpret_cast<const float2*>(&Ar[ml * F_RL + vl]);
+                    v[0] += pv ? a2.x : 0.f; v[1] += pv ? a2.y : 0.f;
+                }
                 if (EPI != FE_PLAIN) {
+                    const float2 x2 = *reinterpret_cast<const float2*>(&Xr[ml * F_RL + vl]);
+                    float2 e2 = make_float2(0.f, 0.f);
+                    if (EPI == FE_RESBWD) e2 = *reinterpret_cast<const float2*>(&Er[ml * F_RL + vl]);
+                    const float xa[2] = {x2.x, x2.y}, ea[2] = {e2.x, e2.y};
 #pragma unroll
                     for (int j2 = 0; j2 < 2; ++j2) {
-                        const float xj = pv ? xv[e][j2] : 0.f;
+                        const float xj = pv ? xa[j2] : 0.f;
                         float mul;                                   // statistics multiplier
                         if (EPI == FE_RESBWD) {
                             v[j2] = (pv && xj > 0.f) ? v[j2] : 0.f;
-                            mul = pv ? ev[e][j2] : 0.f;
+                            mul = pv ? ea[j2] : 0.f;
                         } else {
-                            v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.xact) : 0.f;
+                            v[j2] = pv ? v[j2] * act_bwd(fmaf(esc, xj, esh), A.xact) : 0.f;
                             mul = xj;
                         }
                         s1 += v[j2];
@@ -311,7 +350,8 @@ __global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_k
                     }
                 }
                 if (mv && pv)
-                    *reinterpret_cast<float2*>(A.dx + ((size_t)n * Ci + ml) * (size_t)P + pl) = make_float2(v[0], v[1]);
+                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(dxs) + ((unsigned)ml * (unsigned)P + (unsigned)pl) * 4u) =
+                        make_float2(v[0], v[1]);
                 if (EPI != FE_PLAIN) {
                     s1 = row16_sum(s1);
                     s2 = row16_sum(s2);
@@ -325,30 +365,37 @@ __global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_k
     };
 
     // one partial per (row, 64-voxel tile): the two half-chunk waves of a row are summed (after the chunk's barrier)
-    auto write_stats = [&](int c) {
-        const int n = c / cps, tile = c - n * cps;
-        for (int idx = tid; idx < Ci * 2; idx += 256) {
+    auto write_stats = [&](int n, int tile) {
+        for (int idx = tid; idx < Ci * 2; idx += NT) {
             const int ml = idx >> 1, which = idx & 1;
-            const int lt = ml >> 4, wv = (lt & 1) * 2, j = lt >> 1;
+            const int lt = ml >> 4, wv = (lt % MP) * 2, j = lt / MP;
             const float s = red[((wv * U + j) * 16 + (ml & 15)) * 2 + which] +
                             red[(((wv + 1) * U + j) * 16 + (ml & 15)) * 2 + which];
             A.partial[(((size_t)n * Ci + ml) * A.tiles + tile) * 2 + which] = s;
         }
     };
 
+    // Software pipeline over this workgroup's chunks: the raw rows of chunk c+1 (GEMM operands and epilogue operands)
+    // are requested before the MFMAs of chunk c and converted into the LDS images after its epilogue, so every global
+    // round trip has an MFMA + epilogue phase to complete; no register is live across a phase that does not need it.
     int c = blockIdx.x;
     if (c < total) {
-        fetch(c);
-        for (; c < total; c += G) {
-            store(c);
+        int n = c / cps, tile = c - n * cps;
+        fetch(n, tile * F_PT);
+        for (;;) {
+            store(tile * F_PT);
             __syncthreads();                 // chunk staged
             const int cn = c + G;
-            if (cn < total) fetch(cn);
+            const bool more = cn < total;
+            const int nn = more ? cn / cps : n, ntile = more ? cn - nn * cps : tile;
+            if (more) fetch(nn, ntile * F_PT);
             compute_w();
             compute_d();
-            epilogue(c);
+            epilogue(n, tile);
             __syncthreads();                 // everyone done reading this chunk's images; red[] complete
-            if (EPI != FE_PLAIN) write_stats(c);
+            if (EPI != FE_PLAIN) write_stats(n, tile);
+            if (!more) break;
+            c = cn; n = nn; tile = ntile;
         }
     }
 
@@ -367,11 +414,22 @@ __global__ __launch_bounds__(256, (CO * CI >= 8192) ? 1 : 2) void pw_bwd_fused_k
 
 static int fb_pad32(int c) { return (c + 31) / 32 * 32; }
 
+// residual mode: instantiated only where its three raw tiles fit the LDS (x3d_pw_bwd_fused_ok refuses the others)
+template <int CO, int CI, int NWV, int OCC>
+static void fb_launch_res(const FbArgs& A, dim3 grid, dim3 blk, hipStream_t s) {
+    if constexpr (CI <= 64) {
+        if (A.addend) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_RESBWD, true, NWV, OCC>), grid, blk, 0, s, A);
+        else hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_RESBWD, false, NWV, OCC>), grid, blk, 0, s, A);
+    }
+}
+
 }  // namespace
 
 // shapes the fused kernel is built for: dense, P % 4 == 0, padded (Co, Ci) in the instantiated set
-extern "C" int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P) {
-    if (P % 4 != 0 || P < 4) return 0;
+extern "C" int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P, int mode, int has_addend) {
+    if (P % 4 != 0 || P < 4 || mode < 0 || mode > 2) return 0;
+    if (mode == 2 && Cin > 64) return 0;           // residual mode: three raw fp32 tiles of Cin rows must fit the LDS
+    (void)has_addend;
     const int co = fb_pad32(Cout), ci = fb_pad32(Cin) == 96 ? 128 : fb_pad32(Cin);
     const int cop = co == 96 ? 128 : co;
     if (cop > 128 || ci > 128) return 0;
@@ -402,7 +460,7 @@ extern "C" int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb,
     X3D_CHECK_ARG(mode != 1 || xpre != nullptr);
     X3D_CHECK_ARG(mode != 2 || (ex != nullptr && xpre == nullptr));
     const int P = T * H * W;
-    if (!x3d_pw_bwd_fused_ok(Cin, Cout, P)) {
+    if (!x3d_pw_bwd_fused_ok(Cin, Cout, P, mode, addend != nullptr)) {
         x3d_set_error("x3d_pw_bwd_fused: shape Cin=%d Cout=%d P=%d is outside the fused kernel's set", Cin, Cout, P);
         return X3D_EINVAL;
     }
@@ -411,24 +469,32 @@ extern "C" int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb,
     A.wpartial = wpartial; A.partial = partial; A.ex = ex; A.addend = addend; A.addend_stride = addend_stride;
     A.N = N; A.Co = Cout; A.Ci = Cin; A.P = P; A.tiles = (P + F_PT - 1) / F_PT; A.T = T; A.H = H; A.W = W;
     A.Ho = (H - 1) / 2 + 1; A.Wo = (W - 1) / 2 + 1;
-    const dim3 grid(x3d_pw_bwd_fused_groups(N, P)), block(256);
+    const dim3 grid(x3d_pw_bwd_fused_groups(N, P));
     hipStream_t s = (hipStream_t)stream;
     int co = fb_pad32(Cout), ci = fb_pad32(Cin);
     if (co == 96) co = 128;
     if (ci == 96) ci = 128;
-#define FB_LAUNCH(CO_, CI_)                                                                                     \
-    do {                                                                                                        \
-        if (mode == 0) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, FE_PLAIN>), grid, block, 0, s, A);      \
-        else if (mode == 1) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, FE_ACTBWD>), grid, block, 0, s, A); \
-        else hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, FE_RESBWD>), grid, block, 0, s, A);               \
+#define FB_LAUNCH2(CO_, CI_, EPI_, NWV_, OCC_)                                                                          \
+    do {                                                                                                                    \
+        if (addend) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, EPI_, true, NWV_, OCC_>), grid, blk, 0, s, A);          \
+        else hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, EPI_, false, NWV_, OCC_>), grid, blk, 0, s, A);                \
     } while (0)
-    if (co == 32 && ci == 64) FB_LAUNCH(32, 64);
-    else if (co == 64 && ci == 32) FB_LAUNCH(64, 32);
-    else if (co == 64 && ci == 64) FB_LAUNCH(64, 64);
-    else if (co == 64 && ci == 128) FB_LAUNCH(64, 128);
-    else if (co == 128 && ci == 32) FB_LAUNCH(128, 32);
-    else FB_LAUNCH(128, 64);
+#define FB_LAUNCH(CO_, CI_, NWV_, OCC_)                                                                                  \
+    do {                                                                                                                    \
+        const dim3 blk(64 * NWV_);                                                                                          \
+        if (mode == 0) FB_LAUNCH2(CO_, CI_, FE_PLAIN, NWV_, OCC_);                                                           \
+        else if (mode == 1) FB_LAUNCH2(CO_, CI_, FE_ACTBWD, NWV_, OCC_);                                                     \
+        else fb_launch_res<CO_, CI_, NWV_, OCC_>(A, grid, blk, s);                                                           \
+    } while (0)
+    // narrow shapes (stage 1): 4 waves, 4 workgroups per CU; wide ones (stage 2): 8 waves, 2 workgroups per CU
+    if (co == 32 && ci == 64) FB_LAUNCH(32, 64, 8, 4);
+    else if (co == 64 && ci == 32) FB_LAUNCH(64, 32, 8, 4);
+    else if (co == 64 && ci == 64) FB_LAUNCH(64, 64, 8, 4);
+    else if (co == 64 && ci == 128) FB_LAUNCH(64, 128, 16, 4);
+    else if (co == 128 && ci == 32) FB_LAUNCH(128, 32, 16, 4);
+    else FB_LAUNCH(128, 64, 16, 4);
 #undef FB_LAUNCH
+#undef FB_LAUNCH2
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

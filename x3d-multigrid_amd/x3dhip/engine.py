@@ -129,7 +129,7 @@ _NO_BATCH_REDUCE = os.environ.get("X3D_NO_BATCH_REDUCE", "0") == "1"
 _NO_FUSED_BWD = os.environ.get("X3D_NO_FUSED_BWD", "0") == "1"
 
 
-def _fused_bwd(grads, g, x):
+def _fused_bwd(grads, g, x, mode=0, has_addend=False):
     """Stages 1-2: data gradient and weight gradient of a pointwise conv from one pass (ops.pw_bwd_fused)."""
     if _NO_FUSED_BWD or grads.side is not None or os.environ.get("X3D_EXP_SKIP_WGRAD") == "1":
         return False
@@ -137,7 +137,7 @@ def _fused_bwd(grads, g, x):
         return False
     if tuple(x.shape[2:]) != tuple(g.shape[2:]):
         return False
-    return ops.pw_bwd_fused_ok(x.shape[1], g.shape[1], g[0, 0].numel())
+    return ops.pw_bwd_fused_ok(x.shape[1], g.shape[1], g[0, 0].numel(), mode, has_addend)
 
 
 def _bn_train(partial, bn, S, count, want_nsum=False):
@@ -428,7 +428,7 @@ def _block_backward(rec, dout, grads, below=None):
     cb3 = _bn_bwd(grads, p3, S, P2, blk.bn3, rec["s3"])
 
     # conv3: weight gradient, then data gradient fused with the swish backward (one pass at stages 1-2)
-    if _fused_bwd(grads, g3, a2):
+    if _fused_bwd(grads, g3, a2, mode=1):
         w3 = blk.conv3.weight
         ds, ps, dw3 = ops.pw_bwd_fused(g3, a3, cb3, w3.shape, rec["w3t"], a2, xpre=rec["c2e"], xact=ACT_SWISH, mode=1,
                                        dw_out=grads.out(w3), defer=grads.deferred)
@@ -476,7 +476,8 @@ def _block_backward(rec, dout, grads, below=None):
     cb1 = _bn_bwd(grads, p1, S, P1, blk.bn1, rec["s1"])
 
     # conv1 (+ downsample branch)
-    fuse1 = _fused_bwd(grads, g1, x_raw)
+    mode1 = 2 if _res_fusable(below) else (1 if x_coef is not None else 0)
+    fuse1 = _fused_bwd(grads, g1, x_raw, mode=mode1, has_addend=True)
     if not fuse1:
         _wgrad(grads, blk.conv1.weight, g1, a1, cb1, x_raw, pre=x_coef, pre_act=pre_act)
     if blk.downsample is not None:

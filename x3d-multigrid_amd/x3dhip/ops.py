@@ -193,8 +193,8 @@ def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, ou
     return dw.view(w_shape)
 
 
-def pw_bwd_fused_ok(Cin, Cout, P):
-    return bool(_lib.lib().x3d_pw_bwd_fused_ok(Cin, Cout, P))
+def pw_bwd_fused_ok(Cin, Cout, P, mode=0, has_addend=False):
+    return bool(_lib.lib().x3d_pw_bwd_fused_ok(Cin, Cout, P, mode, 1 if has_addend else 0))
 
 
 def pw_bwd_fused(g, a, cb, w_shape, wpt, x, xpre=None, xact=ACT_NONE, mode=0, ex=None, addend=None, addend_stride=1,
