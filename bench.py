@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the second timed run with the exact fp32-MFMA backward GEMMs")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch HIP-event table (JSON) here")
     args = ap.parse_args()
 
@@ -245,21 +246,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tr.step(x, y)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = tr.step(x, y)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = tdt.item()
+    def timed_run():
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+        for _ in range(args.warmup):
+            tr.step(x, y)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_, _ = tr.step(x, y)
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tdt = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+            dt_ = tdt.item()
+        return dt_, loss_
+
+    dt, loss = timed_run()
     ms = 1000.0 * dt / args.steps
     value = world * B * args.steps / dt
+
+    # the same step with the exact fp32-MFMA backward GEMMs (the switches are read per launch): reported beside the default
+    exact = None
+    if not args.no_exact_fp32:
+        os.environ["X3D_DGRAD_F32"] = "1"
+        os.environ["X3D_WGRAD_F32"] = "1"
+        tr.invalidate_graphs()
+        dt_e, _ = timed_run()
+        exact = (world * B * args.steps / dt_e, 1000.0 * dt_e / args.steps)
+        del os.environ["X3D_DGRAD_F32"], os.environ["X3D_WGRAD_F32"]
+        tr.invalidate_graphs()
 
     E = algorithmic_elems_M(T, H)
     step_bytes = B * 3 * 4 * E + 20 * 3794322
@@ -267,7 +284,10 @@ def main():
         "metric": "clips/sec X3D-M fwd+bwd+SGD at multigrid base shape (whole job)",
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        # storage, forward GEMMs, stencils, BN and the optimizer are fp32; the backward pointwise GEMMs multiply fp32 operands
+        # split into hi + lo bf16 (3 MFMA products, fp32 accumulate, ~2^-16 per product) -- value_exact_fp32 is the same
+        # job with the exact fp32-MFMA backward kernels
+        "dtype": "f32 (backward pointwise GEMMs: split-bf16x3 operands, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": "X3D-M train step B=%d/GPU T=%d H=W=%d, 400 classes, dropout 0.5, SGD momentum" % (B, T, H),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "launch": "eager" if args.no_graph else "hipGraph(fwd+bwd) + SGD",
@@ -275,13 +295,18 @@ def main():
                    # hi+lo bf16 (3 MFMA products, fp32 accumulate, ~2^-16 per product; parity-verified)
                    # unless X3D_DGRAD_F32 / X3D_WGRAD_F32 select the exact fp32-MFMA kernels
                    "backward_gemm": ("fp32 MFMA" if os.environ.get("X3D_DGRAD_F32") else "split-bf16x3 dgrad") + " / " +
-                                    ("fp32 MFMA" if os.environ.get("X3D_WGRAD_F32") else "split-bf16x3 wgrad"),
+                                    ("fp32 MFMA" if os.environ.get("X3D_WGRAD_F32") else "split-bf16x3 wgrad") +
+                                    ("" if (os.environ.get("X3D_DGRAD_F32") or os.environ.get("X3D_NO_FUSED_BWD") == "1")
+                                     else " (stages 1-2: one fused dgrad+wgrad pass)"),
                    "loss": round(float(loss), 4)},
         "step_hbm_roofline": {"algorithmic_bytes_per_step": step_bytes,
                               "achieved_GBs": round(step_bytes / (ms * 1e-3) / 1e9, 1),
                               "frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
+    if exact is not None:
+        out["value_exact_fp32"] = round(exact[0], 2)
+        out["ms_per_step_exact_fp32"] = round(exact[1], 3)
     if not args.no_kernel_timing:
         # one instrumented eager step: HIP events around every launch, same tensors.  EVERY rank runs these steps (they
         # contain the gradient all-reduce: the collectives must match across ranks); only rank 0 records and reports.

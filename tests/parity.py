@@ -48,7 +48,9 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
     floor = abs(float(g["grad_global_norm"]) - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"])
     rep["global_norm_err"] = abs(gg - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"])
     rep["global_norm_floor"] = floor
-    assert rep["global_norm_err"] <= rtol + 3 * floor, rep
+    # the global norm averages the per-element rounding noise out (floor <= 4.6e-4 in every fixture): BASELINE's plain
+    # 1e-3, no noise-floor allowance
+    assert rep["global_norm_err"] < rtol, rep
     # per-parameter norms
     scale = n64 + 1e-6 * float(g["grad_global_norm64"])
     e_got = np.abs(got - n64) / scale

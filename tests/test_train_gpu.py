@@ -180,3 +180,204 @@ def test_training_reduces_loss_on_a_fixed_batch():
     assert losses[0] > 4.5 and losses[-1] < 0.5 * losses[0], losses[::8]
     acc = float((logits.argmax(1) == y).float().mean())
     assert acc >= 0.75, (acc, losses[::8])
+
+
+def _grads_of(env, monkeypatch, x, y, S=1, seed=0):
+    """Flat gradient of one X3D-M step under the given environment switches (read per call by libx3dhip / the engine)."""
+    import x3d as resnet_x3d
+    from x3dhip.trainer import Trainer
+    for k in ("X3D_DGRAD_F32", "X3D_WGRAD_F32", "X3D_NO_FUSED_BWD"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=S)
+    model.load_state_dict(synthetic.procedural_state_dict(xo.state_template("M", 400, S), seed))
+    model.to(x.device).train(True)
+    tr = Trainer(model, lr=0.05, use_graph=False)
+    loss, _ = tr._fwd_bwd(x, y)
+    torch.cuda.synchronize()
+    return float(loss), tr.fp.grad.double().clone()
+
+
+def test_default_backward_gemms_match_exact_fp32_kernels(monkeypatch):
+    """The default backward pointwise GEMMs (split-bf16 x3: fused stage 1-2 kernel, pw5, batched wgrad3) against the
+    exact fp32-MFMA kernels (X3D_DGRAD_F32 / X3D_WGRAD_F32) on a golden shape: <= 1e-4 relative on the whole gradient."""
+    dev = _dev()
+    x = synthetic.synthetic_clips(8, 4, 64, 64, seed=1234).to(dev)
+    y = synthetic.synthetic_labels(8, seed=1234).to(dev)
+    l0, g0 = _grads_of({}, monkeypatch, x, y, S=2)
+    l1, g1 = _grads_of({"X3D_DGRAD_F32": "1", "X3D_WGRAD_F32": "1"}, monkeypatch, x, y, S=2)
+    l2, g2 = _grads_of({"X3D_NO_FUSED_BWD": "1"}, monkeypatch, x, y, S=2)
+    assert abs(l0 - l1) <= 1e-6 * abs(l1)                     # the forward is the same exact-fp32 code
+    assert ((g0 - g1).norm() / g1.norm()).item() < 1e-4
+    assert ((g2 - g1).norm() / g1.norm()).item() < 1e-4
+    assert abs(g0.norm() - g1.norm()) / g1.norm() < 1e-5
+
+
+def test_full_size_multigrid_shape_128x4x111_s8():
+    """BASELINE config 3 at full per-GPU batch, the largest-N shape of the schedule (128, 4, 111, 111) with 8 BN splits
+    (kinetics_multigrid.py:205-237 x cycle_batch_sampler.py:98-111): no golden (the reference needs minutes of CPU), so
+    size-independent properties -- finite loss near log(400), every parameter receives a finite gradient, every split-BN
+    advanced exactly once with 8 splits x C statistics, and two runs are bit-identical."""
+    import x3d as resnet_x3d
+    from x3dhip.trainer import Trainer
+    dev = _dev()
+    x = synthetic.synthetic_clips(128, 4, 111, 111, seed=7).to(dev)
+    y = synthetic.synthetic_labels(128, seed=7).to(dev)
+    runs = []
+    for _ in range(2):
+        model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=8)
+        model.load_state_dict(synthetic.procedural_state_dict(xo.state_template("M", 400, 8), 0))
+        model.to(dev).train(True)
+        tr = Trainer(model, lr=0.05, use_graph=False)
+        loss, logits = tr._fwd_bwd(x, y)
+        torch.cuda.synchronize()
+        sd = model.state_dict()
+        runs.append((float(loss), tr.fp.grad.clone(), logits.clone(), sd))
+    loss, grad, logits, sd = runs[0]
+    assert loss == loss and 4.0 < loss < 8.0
+    assert bool(torch.isfinite(grad).all()) and bool(torch.isfinite(logits).all())
+    assert logits.shape == (128, 400, 1)
+    nz = 0
+    for (o, k) in tr.fp.offsets:
+        nz += int(grad[o:o + k].abs().max() > 0)
+    assert nz == len(tr.fp.offsets)                           # every one of the 316 parameters got a gradient
+    assert sd["layer3.4.bn2.split_bn.running_mean"].shape == (216 * 8,)
+    assert int(sd["bn5.split_bn.num_batches_tracked"]) == 1
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])      # fixed-order reductions
+    for k in ("bn1.split_bn.running_var", "layer4.6.bn3.split_bn.running_mean"):
+        assert torch.equal(runs[0][3][k], runs[1][3][k])
+
+
+def test_large_batch_elementwise_and_finalize_paths():
+    """N * C > 65535 (the documented launch commands put N = 256 ... 2048 clips on a GPU at the first multigrid step):
+    the elementwise / pooling / stem kernels used grid.y = N * C.  One training step at N = 256 (tiny clip, 32 BN splits:
+    bn5 has 432 channels -> N * C = 110592) against the CPU oracle."""
+    import x3d as resnet_x3d
+    dev = _dev()
+    N, T, H, S = 256, 2, 16, 32
+    sd = synthetic.procedural_state_dict(xo.state_template("M", 400, S), 0)
+    model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=S)
+    model.load_state_dict(sd)
+    model.to(dev).train(True)
+    x = synthetic.synthetic_clips(N, T, H, H, seed=11)
+    y = synthetic.synthetic_labels(N, seed=11)
+    logits = model(x.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_logits, ref_loss, ref_grads, _ = xo.train_step_grads(x, y, sd, "M", S)
+    from tests import parity
+    assert parity.rel(logits.detach().cpu().numpy(), ref_logits.numpy()) < 1e-3
+    assert abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()) < 1e-3
+    got = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())).item()
+    ref = torch.sqrt(sum((g.double() ** 2).sum() for g in ref_grads.values())).item()
+    assert abs(got - ref) / ref < 5e-3                        # tiny planes (8 samples x 2 x 1 x 1 voxels per BN group at stage 4)
+
+
+def test_default_batch_arithmetic_runs_step_zero():
+    """run() with the reference's default global batch (128) on ONE rank: step 0 of the schedule is 128 * 8 * 2 = 2048
+    clips with 128 BN splits (train_x3d_kinetics_multigrid.py:51-59, cycle_batch_sampler.py:98-111), at a tiny clip size."""
+    _dev()
+    import train_x3d_kinetics_multigrid as tr
+    steps, cps = tr.run(init_lr=0.01, warmup_steps=5, max_epochs=1, batch_size=128, steps=0, max_steps_run=1,
+                        iterations_per_epoch=40, save_every=0, use_graph=False, log_every=1, clip_size=32)
+    assert steps == 1 and cps > 0
+
+
+def test_graph_cache_released_at_long_cycle_switches():
+    """Captured graphs pin all activations of a step; every long-cycle switch re-creates the split_bn buffers they point
+    at.  Reserved device memory must stay flat across many switches (the cache is dropped at each one)."""
+    import x3d as resnet_x3d
+    from x3dhip.trainer import Trainer
+    dev = _dev()
+    model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=1).to(dev).train(True)
+    tr = Trainer(model, lr=0.01, use_graph=True)
+    x = synthetic.synthetic_clips(8, 4, 64, 64, seed=3).to(dev)
+    y = synthetic.synthetic_labels(8, seed=3).to(dev)
+    reserved = []
+    for sw in range(7):
+        model.update_bn_splits_long_cycle([1, 2, 4, 8][sw % 4])
+        tr.invalidate_graphs()
+        for _ in range(2):
+            tr.train_step(x, y)
+        torch.cuda.synchronize()
+        assert len(tr._graphs) == 1
+        reserved.append(torch.cuda.memory_reserved())
+    assert max(reserved[1:]) <= 1.10 * reserved[1] + (64 << 20), reserved
+    # the safety net: a version bump without an explicit invalidate also drops the stale entries at the next lookup
+    model.update_bn_splits_long_cycle(2)
+    tr.train_step(x, y)
+    assert len(tr._graphs) == 1
+
+
+def test_gradient_accumulation_equals_one_big_step():
+    """num_steps_per_update = 2 on two half batches == the gradient of loss/2 + loss/2 (train...:267-273): the update equals
+    an SGD step on the mean of the two micro-batch gradients."""
+    import x3d as resnet_x3d
+    from x3dhip.trainer import Trainer
+    dev = _dev()
+    sd = synthetic.procedural_state_dict(xo.state_template("M", 400, 1), 0)
+    xs = [synthetic.synthetic_clips(4, 4, 48, 48, seed=s).to(dev) for s in (1, 2)]
+    ys = [synthetic.synthetic_labels(4, seed=s).to(dev) for s in (1, 2)]
+
+    def fresh(**kw):
+        m = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=1)
+        m.load_state_dict(sd)
+        m.to(dev).train(True)
+        return m, Trainer(m, lr=0.05, **kw)
+
+    m1, t1 = fresh(num_steps_per_update=2, use_graph=True)
+    t1.train_step(xs[0], ys[0])
+    assert not t1.stepped
+    w_before = t1.fp.flat.clone()
+    assert torch.equal(w_before, fresh()[1].fp.flat)             # the first micro-batch does not move the parameters
+    t1.train_step(xs[1], ys[1])
+    assert t1.stepped
+    # reference: the two gradients by separate eager passes, averaged, one fused SGD step
+    m2, t2 = fresh()
+    _, _ = t2._fwd_bwd(xs[0], ys[0])
+    g0 = t2.fp.grad.clone()
+    _, _ = t2._fwd_bwd(xs[1], ys[1])
+    g = 0.5 * (g0 + t2.fp.grad)
+    expect = w_before - 0.05 * (g + 5e-5 * w_before)
+    torch.cuda.synchronize()
+    assert ((t1.fp.flat - expect).norm() / (0.05 * g.norm())).item() < 1e-4
+
+
+def test_rccl_world_size_one_split_graph(monkeypatch):
+    """Backend "nccl" IS RCCL on ROCm: a one-rank process group drives the real data-parallel path -- two captured graphs
+    with ncclAllReduce of the first gradient bucket on the communication stream between the replays (thread-local
+    capture), second bucket after graph B -- and must give bit-identical gradients and weights to the single graph."""
+    import torch.distributed as dist
+    import x3d as resnet_x3d
+    from x3dhip.trainer import Trainer
+    dev = _dev()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29531")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    x = synthetic.synthetic_clips(4, 4, 64, 64, seed=5).to(dev)
+    y = synthetic.synthetic_labels(4, seed=5).to(dev)
+    res = []
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for split in (False, True):
+            if split:
+                monkeypatch.setenv("X3D_FORCE_SPLIT", "1")
+            else:
+                monkeypatch.delenv("X3D_FORCE_SPLIT", raising=False)
+            model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=2)
+            model.load_state_dict(synthetic.procedural_state_dict(xo.state_template("M", 400, 2), 1))
+            model.to(dev).train(True)
+            monkeypatch.setenv("X3D_FORCE_COLLECTIVES", "1" if split else "0")      # one-rank group: still all-reduce
+            tr = Trainer(model, lr=0.05, use_graph=True, process_group=dist.group.WORLD, world_size=1)
+            assert tr.reducer.active == split and tr._overlap() == split
+            for _ in range(3):
+                loss, _ = tr.train_step(x, y)
+            torch.cuda.synchronize()
+            res.append((float(loss), tr.fp.grad.clone(), tr.fp.flat.clone()))
+    finally:
+        dist.destroy_process_group()
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
+    assert torch.equal(res[0][1], res[1][1])                   # sum over one rank == identity: bit-identical
+    assert torch.equal(res[0][2], res[1][2])

@@ -61,13 +61,16 @@ class GradReducer:
 
     def __init__(self, flat_grad, buckets, world_size, process_group=None):
         self.flat_grad, self.buckets, self.world, self.pg = flat_grad, buckets, world_size, process_group
-        self.stream = torch.cuda.Stream() if (world_size > 1 and flat_grad.is_cuda) else None
+        # X3D_FORCE_COLLECTIVES=1: issue the all-reduces on a one-rank group too (a sum over one rank is the identity) --
+        # how the RCCL path (backend "nccl") is exercised on a single-GPU box (tests/test_train_gpu.py)
+        self.active = world_size > 1 or (process_group is not None and os.environ.get("X3D_FORCE_COLLECTIVES") == "1")
+        self.stream = torch.cuda.Stream() if (self.active and flat_grad.is_cuda) else None
 
     def buffers_like(self):
         return list(self.buckets)
 
     def reduce(self):
-        if self.world <= 1:
+        if not self.active:
             return
         import torch.distributed as dist
         if self.stream is None:                       # CPU tensors (gloo)
@@ -85,7 +88,7 @@ class GradReducer:
         """Enqueue the all-reduce of bucket i behind everything on the current stream WITHOUT making the current
         stream wait for it: the caller keeps launching backward kernels (x3dhip.trainer: the early layers) while
         the bucket travels over xGMI.  finish() joins."""
-        if self.world <= 1:
+        if not self.active:
             return
         import torch.distributed as dist
         a, b = self.buckets[i]
@@ -97,7 +100,7 @@ class GradReducer:
             dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.pg)
 
     def finish(self):
-        if self.world > 1 and self.stream is not None:
+        if self.active and self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
 
 
