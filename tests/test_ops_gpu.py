@@ -63,6 +63,13 @@ PW_CASES = [
     (20, 128, 96, 4, 16, 16, 1, 1),   # persistent tiled kernel: 4 chunks per item, 6 M-tiles (U = 3), item list with a tail
     (2, 48, 96, 4, 16, 16, 2, 1),     # stride 2 with P_out % 4 == 0: gathered-input weight-gradient kernel (downsample branch)
     (3, 24, 24, 2, 12, 20, 2, 0),     # same, narrow channels (64 x 32 tile), raw input
+    # X3D-S eval, stage 4 at 2 x 13 x 160^2 (P = 13 * 5 * 5 = 325, P % 4 != 0): M = 432 is 27 sixteen-row tiles in 4 blocks
+    # of 7, so the last block owns a tile index (27) past the packed image.  Round 1's first tiled kernel (commits
+    # 48232ad..cf54da2) read that tile's fragments unclamped -- up to 12 KiB beyond the pack allocation, results never
+    # stored -- which aborted tests/test_model_gpu.py::test_eval_forward_config1_S whenever the fresh pack sat at the end
+    # of a mapped segment (gpurun_out/all23.log); every kernel has clamped the tile index since 3e45adf
+    (2, 192, 432, 13, 5, 5, 1, 1),
+    (2, 432, 192, 13, 5, 5, 1, 2),
 ]
 
 

@@ -21,6 +21,12 @@
 #include <cstdlib>
 #include "common.h"
 
+// pw6.hip: forward kernel of the large-channel layers (whole-K items, 3-term split-bf16 MFMA)
+bool x3d_pw6_ok(int K, int M, int P);
+int x3d_pw6_tiles(int P);
+int x3d_pw6_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M,
+                   int P, int in_act, hipStream_t s);
+
 namespace {
 
 enum { IN_RAW = 0, IN_AFFACT = 1, IN_BNBWD = 2 };
@@ -563,16 +569,24 @@ __device__ __forceinline__ void pack_item(int i, const float* __restrict__ w, fl
     const __bf16 h = (__bf16)v;
     __bf16* wq = reinterpret_cast<__bf16*>(wp + nf);
     wq[t] = h;
-    wq[nq + t] = (__bf16)(v - (float)h);
+    if (with_bf16 == 3) {           // forward packs: three planes hi + mid + lo = all 24 significant bits (pw6_kernel)
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        wq[nq + t] = m;
+        wq[2 * nq + t] = (__bf16)(r1 - (float)m);
+    } else {                        // transposed packs: hi + lo (16 bits) for the backward kernels
+        wq[nq + t] = (__bf16)(v - (float)h);
+    }
 }
 
-static size_t pack_items(int K, int M, int with_bf16) {
+// planes: 2 (transposed packs: hi, lo) or 3 (forward packs: hi, mid, lo)
+static size_t pack_items(int K, int M, int planes) {
     const size_t mt = cdiv(M, 16);
-    return mt * cdiv(K, 16) * 256 + (with_bf16 ? mt * cdiv(K, 32) * 512 : 0);
+    return mt * cdiv(K, 16) * 256 + (planes ? mt * cdiv(K, 32) * 512 : 0);
 }
-static size_t pack_floats(int K, int M, int with_bf16) {
+static size_t pack_floats(int K, int M, int planes) {
     const size_t mt = cdiv(M, 16);
-    return mt * cdiv(K, 16) * 256 + (with_bf16 ? mt * cdiv(K, 32) * 512 : 0);     // two bf16 planes = one float per (hi, lo) pair
+    return mt * cdiv(K, 16) * 256 + mt * cdiv(K, 32) * 256 * (size_t)planes;        // a bf16 plane = 256 floats per (tile, k step)
 }
 
 __global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int M, int K,
@@ -2251,10 +2265,16 @@ extern "C" int x3d_pw_tiles(int N, int K, int M, int P, int dense) {
     return tiles;
 }
 
+// tiles of the forward's `partial`: the large-channel forward kernel (packed weights, dense) works on 32-voxel items
+extern "C" int x3d_pw_fwd_tiles(int N, int Cin, int Cout, int P, int dense, int packed) {
+    if (packed && dense && x3d_pw6_ok(Cin, Cout, P)) return x3d_pw6_tiles(P);
+    return x3d_pw_tiles(N, Cin, Cout, P, dense);
+}
+
 extern "C" int x3d_pw_wants_packed(int K, int M) { (void)K; (void)M; return 1; }
 
-extern "C" size_t x3d_pw_pack_floats(int K, int M, int transposed) { return pack_floats(K, M, transposed); }
-extern "C" size_t x3d_pw_pack_items(int K, int M, int transposed) { return pack_items(K, M, transposed); }
+extern "C" size_t x3d_pw_pack_floats(int K, int M, int transposed) { return pack_floats(K, M, transposed ? 2 : 3); }
+extern "C" size_t x3d_pw_pack_items(int K, int M, int transposed) { return pack_items(K, M, transposed ? 2 : 3); }
 
 extern "C" int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int transposed, void* stream) {
     X3D_CHECK_ARG(w && wp && Cout > 0 && Cin > 0);
@@ -2263,8 +2283,8 @@ extern "C" int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int tra
     const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
     const int ldm = transposed ? 1 : Cin, ldk = transposed ? Cin : 1;
     const int mtiles = cdiv(M, 16), kgroups = cdiv(K, 16);
-    hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)cdiv((int)pack_items(K, M, transposed), 256)), dim3(256), 0,
-                       (hipStream_t)stream, w, wp, M, K, ldm, ldk, mtiles, kgroups, transposed ? 1 : 0);
+    hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)cdiv((int)pack_items(K, M, transposed ? 2 : 3), 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, wp, M, K, ldm, ldk, mtiles, kgroups, transposed ? 2 : 3);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
@@ -2293,6 +2313,8 @@ extern "C" int x3d_pw_fwd(const float* x, const float* w, const float* wpacked, 
     A.in_act = pre_act; A.strided = strideHW == 2; A.T = T; A.H = H; A.W = W; A.Ho = Ho; A.Wo = Wo;
     A.partial = partial; A.addend = nullptr; A.addend_stride = 1;
     hipStream_t s = (hipStream_t)stream;
+    if (wpacked != nullptr && strideHW == 1 && x3d_pw6_ok(Cin, Cout, A.P))
+        return x3d_pw6_launch(x, pre, wpacked, y, partial, N, Cin, Cout, A.P, pre_act, s);
     if (pre) return launch_pw<IN_AFFACT, EPI_STATS>(A, s);
     return launch_pw<IN_RAW, EPI_STATS>(A, s);
 }

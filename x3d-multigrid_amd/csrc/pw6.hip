@@ -1,0 +1,227 @@
+// Forward pointwise (1x1x1) convolution for the large-channel layers (stages 3-4, conv5: K >= 64, M >= 96, dense,
+// P % 4 == 0) -- conv1x1x1 (x3d.py:98-103) as Bottleneck.conv1 / conv3 (:112,116,146,162) and conv5 (:231,327), with the
+// producer's BN-apply + ReLU / BN*SE + Swish fused on load and the BN statistics of the output in the epilogue.
+//
+// These layers are small problems (10-22 MB tensors, 0.5-1 GFLOP): what bounds a kernel here is its chain of exposed
+// latencies, not bytes or FLOPs.  pw4_kernel walks K in 32-channel chunks with one global round trip per chunk and does the
+// GEMM on the fp32 MFMA (1/16 of the bf16 rate), 25-30 us per launch.  Here
+//   * a work item is (sample, 32-voxel tile, block of <= 8 sixteen-row M tiles) and its WHOLE K is requested in one burst
+//     (K x 32 voxels: 12-55 KB per workgroup, 8 waves): one global round trip per item, 1500-3000 items per launch;
+//   * the activation tile is split while it is staged, x = hi + mid + lo (three bf16 = all 24 significant bits), into three
+//     LDS planes in [channel][voxel] order and read TRANSPOSED (ds_read_b64_tr_b16) as the B operand; the weights come
+//     pre-split the same way (x3d_pw_pack, forward image, L2 resident) through a 4-deep register ring -- the only vector
+//     memory traffic during the K loop, so the in-order vmcnt never waits on anything younger;
+//   * every 16x16x32 tile product is six bf16 MFMAs (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, smallest first, fp32
+//     accumulate): the dropped terms are <= 2^-24 relative -- fp32 rounding level (the 2-term split of the backward
+//     kernels is not accurate enough for the forward) -- at 3/8 of the fp32-MFMA cycles;
+//   * wave w owns M tile w of the block and both 16-voxel column tiles: a row's statistics are complete inside one wave
+//     (16-lane DPP row sum), no cross-wave combine, no second barrier.
+// Voxel v of the tile sits at LDS column (v & 1) * 16 + (v >> 1), so a lane owns voxels 2r, 2r+1 (float2 stores).
+#include <cstdlib>
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+struct P6Args {
+    const float* x;       // [N][K][P]
+    const float* cin;     // [N][K][2] or NULL
+    const float* wp;      // forward pack: fp32 image, then bf16 hi / mid / lo planes
+    float* y;             // [N][M][P]
+    float* partial;       // [N][M][tiles][2] or NULL
+    int N, K, M, P, tiles, in_act, mblocks, mt_run;
+};
+
+constexpr int P6_BN = 32;          // voxels per item
+constexpr int P6_LD = 40;          // bf16 elements per LDS row (80 B; 72 B rows + 3 workgroups per CU measured slower: the CU is throughput bound)
+constexpr int P6_NT = 512;         // threads (8 waves)
+constexpr int P6_RP = P6_NT / 8;   // rows staged per pass (8 lanes x float4 = one 32-voxel row)
+constexpr int P6_MAXPASS = 7;      // K <= 448
+
+__device__ __forceinline__ bf16x8 cat8_(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+template <int IN_AFF, int NPASS>
+__global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int K = A.K, P = A.P, M = A.M;
+    const int kg32 = (K + 31) / 32, kg16 = (K + 15) / 16, Kp = kg32 * 32;
+    __bf16* Xh = lds6;
+    __bf16* Xm = lds6 + (size_t)Kp * P6_LD;
+    __bf16* Xl = lds6 + (size_t)2 * Kp * P6_LD;
+
+    // item = ((voxel-tile group of 8) * mblocks + mb) * 8 + (voxel tile & 7): the M blocks of one voxel tile get ids 8 apart
+    // (round-robin dispatch: the same XCD, so its activation tile is fetched into that L2 once)
+    const int VT = A.N * A.tiles;
+    const int it = blockIdx.x;
+    const int tlo = it & 7, rest = it >> 3;
+    const int mb = rest % A.mblocks, vt = (rest / A.mblocks) * 8 + tlo;
+    if (vt >= VT) return;
+    const int n = vt / A.tiles, tile = vt - n * A.tiles;
+    const int pt = tile * P6_BN;
+
+    // ---- stage: whole K x 32 voxels in one burst
+    const int c4 = (tid & 7) * 4, row0 = tid >> 3;
+    const int pc = min(pt + c4, P - 4);
+    const bool pvv = pt + c4 < P;
+    const int colE = c4 >> 1, colO = colE + 16;
+    const float* xs = A.x + (size_t)n * K * (size_t)P;
+    const float* cs = IN_AFF ? A.cin + (size_t)n * K * 2 : nullptr;
+    float4 rx[NPASS];
+    float2 cf[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const unsigned k = (unsigned)min(row0 + P6_RP * i, K - 1);
+        rx[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xs) + (k * (unsigned)P + (unsigned)pc) * 4u);
+        if (IN_AFF) cf[i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cs) + k * 8u);
+    }
+    // this wave's A fragments: M tile (block mb, wave), planes behind the fp32 image of the pack
+    const int mtiles = (M + 15) / 16;
+    const int mt = min(mb * A.mt_run + wave, mtiles - 1);                      // clamped: a duplicate is never stored
+    const bool mt_ok = wave < A.mt_run && mb * A.mt_run + wave < mtiles;
+    const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
+    const size_t plane = (size_t)mtiles * kg32 * 512;
+    const __bf16* wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;                // + s * 512 per k step, + plane per plane
+    bf16x8 ah[4], am[4], al[4];
+    auto fetch_a = [&](int s, bf16x8& h, bf16x8& m, bf16x8& l) {
+        const int sc = min(s, kg32 - 1);
+        h = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512);
+        m = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512 + plane);
+        l = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512 + 2 * plane);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fetch_a(i, ah[i], am[i], al[i]);               // in flight behind the activation burst
+
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int row = row0 + P6_RP * i;
+        if (row < Kp) {
+            const bool ok = pvv && row < K;
+            float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+            if (IN_AFF) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(cf[i].x, v[e], cf[i].y), A.in_act);
+            }
+            bf16x2 he, ho, me, mo, le, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = ok ? v[e] : 0.f;
+                const __bf16 h = (__bf16)x0;
+                const float r1 = x0 - (float)h;
+                const __bf16 m = (__bf16)r1;
+                const __bf16 l = (__bf16)(r1 - (float)m);
+                if (e & 1) { ho[e >> 1] = h; mo[e >> 1] = m; lo[e >> 1] = l; } else { he[e >> 1] = h; me[e >> 1] = m; le[e >> 1] = l; }
+            }
+            *reinterpret_cast<bf16x2*>(&Xh[row * P6_LD + colE]) = he;
+            *reinterpret_cast<bf16x2*>(&Xh[row * P6_LD + colO]) = ho;
+            *reinterpret_cast<bf16x2*>(&Xm[row * P6_LD + colE]) = me;
+            *reinterpret_cast<bf16x2*>(&Xm[row * P6_LD + colO]) = mo;
+            *reinterpret_cast<bf16x2*>(&Xl[row * P6_LD + colE]) = le;
+            *reinterpret_cast<bf16x2*>(&Xl[row * P6_LD + colO]) = lo;
+        }
+    }
+    __syncthreads();
+
+    // ---- K loop: B fragments by transposed LDS reads, A fragments through the register ring
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int tr_off = (8 * q + (r >> 2)) * P6_LD + 4 * (r & 3);
+    auto tr_frag = [&](const __bf16* pl, int s, int h2) -> bf16x8 {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const __bf16* p0 = pl + 32 * s * P6_LD + tr_off + 16 * h2;
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * P6_LD));
+        return cat8_(v0, v1);
+    };
+    auto step = [&](int s, const bf16x8& h, const bf16x8& m, const bf16x8& l) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const bf16x8 bh = tr_frag(Xh, s, h2), bm = tr_frag(Xm, s, h2), bl = tr_frag(Xl, s, h2);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l, bh, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bl, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m, bm, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m, bh, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bm, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bh, acc[h2], 0, 0, 0);
+        }
+    };
+    if (mt_ok) {                                  // wave-uniform: waves beyond the block's tiles only helped staging
+        for (int s0 = 0; s0 < kg32; s0 += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (s0 + i < kg32) {
+                    step(s0 + i, ah[i], am[i], al[i]);
+                    if (s0 + i + 4 < kg32) fetch_a(s0 + i + 4, ah[i], am[i], al[i]);
+                }
+            }
+        }
+
+        // ---- epilogue: lane (q, r) holds rows 4 q + e of the tile and voxels 2 r (acc[0]), 2 r + 1 (acc[1])
+        const int pl = pt + 2 * r;
+        const bool pv = pl < P;                   // P even: both voxels or none
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = mt * 16 + 4 * q + e;
+            const bool mv = m < M;
+            const float v0 = pv ? acc[0][e] : 0.f, v1 = pv ? acc[1][e] : 0.f;
+            if (mv && pv) *reinterpret_cast<float2*>(A.y + ((size_t)n * M + m) * (size_t)P + pl) = make_float2(v0, v1);
+            if (A.partial != nullptr) {
+                const float s1 = row16_sum(v0 + v1);
+                const float s2 = row16_sum(fmaf(v0, v0, v1 * v1));
+                if (r == 0 && mv) {
+                    float* pp = A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2;
+                    pp[0] = s1; pp[1] = s2;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// shapes pw6 takes (the caller has checked: dense, packed weights present)
+bool x3d_pw6_ok(int K, int M, int P) {
+    static const bool off = getenv("X3D_NO_PW6") != nullptr;
+    return !off && K >= 64 && K <= P6_RP * P6_MAXPASS && M >= 96 && (P % 4 == 0) && P >= 4;
+}
+
+int x3d_pw6_tiles(int P) { return cdiv(P, P6_BN); }
+
+int x3d_pw6_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M,
+                   int P, int in_act, hipStream_t s) {
+    P6Args A = {};
+    A.x = x; A.cin = cin; A.wp = wp; A.y = y; A.partial = partial;
+    A.N = N; A.K = K; A.M = M; A.P = P; A.tiles = cdiv(P, P6_BN); A.in_act = in_act;
+    const int mtiles = cdiv(M, 16);
+    A.mblocks = cdiv(mtiles, 8);
+    A.mt_run = cdiv(mtiles, A.mblocks);
+    const int VT = N * A.tiles;
+    const dim3 grid(cdiv(VT, 8) * 8 * A.mblocks), block(P6_NT);
+    const int kp = cdiv(K, 32) * 32;
+    const size_t lds = (size_t)3 * kp * P6_LD * sizeof(__bf16);
+    const int npass = cdiv(kp, P6_RP);
+    // more than 64 KB of dynamic LDS (K > 256) has to be allowed per kernel once
+#define P6_GO(AFF, NP)                                                                                              \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw6_kernel<AFF, NP>),                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P6_RP * NP * P6_LD * 2);       \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((pw6_kernel<AFF, NP>), grid, block, lds, s, A);                                           \
+    } while (0)
+#define P6_PASS(AFF)                                                                             \
+    do {                                                                                         \
+        if (npass <= 2) P6_GO(AFF, 2); else if (npass <= 4) P6_GO(AFF, 4); else P6_GO(AFF, 7);   \
+    } while (0)
+    if (cin) P6_PASS(1); else P6_PASS(0);
+#undef P6_PASS
+#undef P6_GO
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}

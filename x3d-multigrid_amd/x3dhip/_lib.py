@@ -29,6 +29,7 @@ SIGNATURES = {
     "x3d_clip_preprocess": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "x3d_last_error": (ctypes.c_char_p, []),
     "x3d_pw_tiles": (_I, [_I, _I, _I, _I, _I]),
+    "x3d_pw_fwd_tiles": (_I, [_I, _I, _I, _I, _I, _I]),
     "x3d_pw_wants_packed": (_I, [_I, _I]),
     "x3d_pw_pack_floats": (_Z, [_I, _I, _I]),
     "x3d_pw_pack_items": (_Z, [_I, _I, _I]),

@@ -78,7 +78,8 @@ def pw_fwd(x, w, stride=1, pre=None, pre_act=ACT_NONE, want_stats=True, out=None
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
     y = out if out is not None else _f((N, Cout, T, Ho, Wo), x)
     if want_stats and partial is None:
-        partial = _f((N, Cout, L.x3d_pw_tiles(N, Cin, Cout, T * Ho * Wo, 1 if stride == 1 else 0), 2), x)
+        partial = _f((N, Cout, L.x3d_pw_fwd_tiles(N, Cin, Cout, T * Ho * Wo, 1 if stride == 1 else 0,
+                                                  1 if wp is not None else 0), 2), x)
     check(L.x3d_pw_fwd(ptr(x), ptr(w), ptr(wp), ptr(y), N, Cin, Cout, T, H, W, stride, ptr(pre), pre_act,
                        ptr(partial) if want_stats else None, _lib.stream()))
     return y, (partial if want_stats else None)
