@@ -56,6 +56,8 @@ const char* x3d_last_error(void);
 int x3d_pw_tiles(int N, int K, int M, int P, int dense);
 /* tiles of x3d_pw_fwd's `partial` (packed = 1 when wpacked is passed: the large-channel layers then run on 32-voxel items) */
 int x3d_pw_fwd_tiles(int N, int Cin, int Cout, int P, int dense, int packed);
+/* tiles of x3d_pw_bwd_data's / x3d_pw_bwd_data_res's `partial` (packed = 1 when wpacked_t is passed) */
+int x3d_pw_bwd_tiles(int N, int Cin, int Cout, int P, int packed);
 
 /* Forward.  in[ci,p] = act(pre[n,ci,0] * x + pre[n,ci,1]) when pre != NULL (fuses the
  * producer's BN-apply + ReLU, or BN-apply * SE-scale + Swish: x3d.py:147-148,151-160), else x.

@@ -26,6 +26,10 @@ bool x3d_pw6_ok(int K, int M, int P);
 int x3d_pw6_tiles(int P);
 int x3d_pw6_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M,
                    int P, int in_act, hipStream_t s);
+bool x3d_pw7_ok(int K, int M, int P);
+int x3d_pw7_launch(const float* g, const float* a, const float* cb, const float* wpt, float* out, float* partial, int mode,
+                   const float* ex, const float* emask, const float* ecoef, int e_act, const float* addend,
+                   int addend_stride, int N, int K, int M, int T, int H, int W, hipStream_t s);
 
 namespace {
 
@@ -2271,6 +2275,12 @@ extern "C" int x3d_pw_fwd_tiles(int N, int Cin, int Cout, int P, int dense, int 
     return x3d_pw_tiles(N, Cin, Cout, P, dense);
 }
 
+// tiles of the data gradient's `partial` (Cout = its K, Cin = its M)
+extern "C" int x3d_pw_bwd_tiles(int N, int Cin, int Cout, int P, int packed) {
+    if (packed && x3d_pw7_ok(Cout, Cin, P)) return x3d_pw6_tiles(P);
+    return x3d_pw_tiles(N, Cout, Cin, P, 1);
+}
+
 extern "C" int x3d_pw_wants_packed(int K, int M) { (void)K; (void)M; return 1; }
 
 extern "C" size_t x3d_pw_pack_floats(int K, int M, int transposed) { return pack_floats(K, M, transposed ? 2 : 3); }
@@ -2336,6 +2346,9 @@ extern "C" int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, 
     A.partial = partial; A.ex = x; A.ecoef = pre; A.e_act = pre_act;
     A.addend = addend; A.addend_stride = addend_stride;
     hipStream_t s = (hipStream_t)stream;
+    if (wpacked_t != nullptr && x3d_pw7_ok(Cout, Cin, A.P))
+        return x3d_pw7_launch(g, a, cb, wpacked_t, out, partial, pre ? 1 : 0, x, nullptr, pre, pre_act, addend, addend_stride,
+                              N, Cout, Cin, T, H, W, s);
     if (pre) return launch_pw<IN_BNBWD, EPI_ACTBWD>(A, s);
     return launch_pw<IN_BNBWD, EPI_PLAIN>(A, s);
 }
@@ -2354,6 +2367,9 @@ extern "C" int x3d_pw_bwd_data_res(const float* g, const float* a, const float* 
     A.Ho = (H - 1) / 2 + 1; A.Wo = (W - 1) / 2 + 1;
     A.partial = partial; A.ex = res_raw; A.emask = res_out; A.ecoef = nullptr; A.e_act = X3D_ACT_RELU;
     A.addend = addend; A.addend_stride = addend_stride;
+    if (wpacked_t != nullptr && x3d_pw7_ok(Cout, Cin, A.P))
+        return x3d_pw7_launch(g, a, cb, wpacked_t, out, partial, 2, res_raw, res_out, nullptr, X3D_ACT_RELU, addend,
+                              addend_stride, N, Cout, Cin, T, H, W, (hipStream_t)stream);
     return launch_pw<IN_BNBWD, EPI_RESBWD>(A, (hipStream_t)stream);
 }
 

@@ -181,6 +181,214 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Data gradient of the same layers (ConvolutionBackward grad_input of conv1x1x1, x3d.py:98-103, fused with the BN backward
+// in front and the activation / residual backward behind it exactly as pw5_kernel in pw.hip): the whole-K item structure
+// above with dY = cb0*g + cb1*a + cb2 staged as TWO bf16 planes (hi + lo, 3 MFMA products: the backward kernels'
+// precision), the transposed weight pack as A operand, and the epilogue operands (raw x / ReLU mask /
+// statistics multiplier / addend) requested behind the first A fragments so that they land during the K loop.
+// pw5_kernel walks K in 32-channel chunks with ONE global round trip per chunk (its MFMA phase is 0.1 us): 7-14 serialised
+// memory latencies per item; here an item pays one.
+// ---------------------------------------------------------------------------------------
+enum { P7_PLAIN = 0, P7_ACTBWD = 1, P7_RESBWD = 2 };
+
+struct P7Args {
+    const float* g; const float* a; const float* cb;      // [N][K][P], [N][K][P], [N][K][3]
+    const float* wp;                                       // transposed pack (M = Cin rows, K = Cout)
+    float* y;                                              // [N][M][P]
+    float* partial;                                        // [N][M][tiles][2] (ACTBWD / RESBWD)
+    const float* ex;                                       // ACTBWD: raw x; RESBWD: raw conv3 output of the producing block
+    const float* emask;                                    // RESBWD: that block's output
+    const float* ecoef; int e_act;                         // ACTBWD: [N][M][2]
+    const float* addend; int addend_stride;
+    int N, K, M, P, tiles, T, H, W, Ho, Wo, mblocks, mt_run;
+};
+
+template <int EPI, int NPASS>
+__global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const P7Args A) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int K = A.K, P = A.P, M = A.M;
+    const int kg32 = (K + 31) / 32, kg16 = (K + 15) / 16, Kp = kg32 * 32;
+    __bf16* Dh = lds6;
+    __bf16* Dl = lds6 + (size_t)Kp * P6_LD;
+
+    const int VT = A.N * A.tiles;
+    const int it = blockIdx.x;
+    const int tlo = it & 7, rest = it >> 3;
+    const int mb = rest % A.mblocks, vt = (rest / A.mblocks) * 8 + tlo;
+    if (vt >= VT) return;
+    const int n = vt / A.tiles, tile = vt - n * A.tiles;
+    const int pt = tile * P6_BN;
+
+    // ---- stage dY: whole K x 32 voxels of g and a in one burst
+    {
+        const int c4 = (tid & 7) * 4, row0 = tid >> 3;
+        const int pc = min(pt + c4, P - 4);
+        const bool pvv = pt + c4 < P;
+        const int colE = c4 >> 1, colO = colE + 16;
+        const float* gs = A.g + (size_t)n * K * (size_t)P;
+        const float* as = A.a + (size_t)n * K * (size_t)P;
+        const float* cs = A.cb + (size_t)n * K * 3;
+        float4 rg[NPASS], ra[NPASS];
+        float k0[NPASS], k1[NPASS], k2[NPASS];
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const unsigned k = (unsigned)min(row0 + P6_RP * i, K - 1);
+            const unsigned off = (k * (unsigned)P + (unsigned)pc) * 4u;
+            rg[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gs) + off);
+            ra[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(as) + off);
+            const float* c3 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(cs) + k * 12u);
+            k0[i] = c3[0]; k1[i] = c3[1]; k2[i] = c3[2];
+        }
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int row = row0 + P6_RP * i;
+            if (row < Kp) {
+                const bool ok = pvv && row < K;
+                const float gv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w}, av[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                bf16x2 he, ho, le, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
+                    const __bf16 h = (__bf16)x0;
+                    const __bf16 l = (__bf16)(x0 - (float)h);
+                    if (e & 1) { ho[e >> 1] = h; lo[e >> 1] = l; } else { he[e >> 1] = h; le[e >> 1] = l; }
+                }
+                *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colE]) = he;
+                *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colO]) = ho;
+                *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colE]) = le;
+                *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colO]) = lo;
+            }
+        }
+    }
+
+    // ---- this wave's A fragments (first ring entries), then the epilogue operands: both in flight across the barrier
+    const int mtiles = (M + 15) / 16;
+    const int mt = min(mb * A.mt_run + wave, mtiles - 1);                      // clamped: a duplicate is never stored
+    const bool mt_ok = wave < A.mt_run && mb * A.mt_run + wave < mtiles;
+    const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
+    const size_t plane = (size_t)mtiles * kg32 * 512;
+    const __bf16* wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;
+    bf16x8 ah[4], al[4];
+    auto fetch_a = [&](int s, bf16x8& h, bf16x8& l) {
+        const int sc = min(s, kg32 - 1);
+        h = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512);
+        l = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512 + plane);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fetch_a(i, ah[i], al[i]);
+
+    const int pl = pt + 2 * r;                    // lane (q, r): rows 4 q + e of the tile, voxels 2 r, 2 r + 1
+    const bool pv = pl < P;                       // P even: both voxels or none
+    const int pc2 = pv ? pl : 0;
+    const bool has_add = A.addend != nullptr;
+    const bool add_s2 = has_add && A.addend_stride == 2;
+    int aoff[2] = {pc2, pc2 + 1};
+    bool av[2] = {has_add && pv, has_add && pv};
+    if (add_s2) {
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {
+            const int p = pc2 + j2;
+            const int hw = A.H * A.W;
+            const int t = p / hw, rem = p - t * hw;
+            const int h = rem / A.W, w = rem - h * A.W;
+            const bool even = !(h & 1) && !(w & 1);
+            av[j2] = av[j2] && even;
+            aoff[j2] = even ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0;
+        }
+    }
+    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+    float xv[4][2], mk[4][2], adv[4][2], esc[4], esh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = mt * 16 + 4 * q + e;
+        const size_t mrow = (size_t)n * M + (m < M ? m : 0);
+        if (EPI == P7_ACTBWD) {
+            const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
+            esc[e] = c2.x; esh[e] = c2.y;
+        }
+        if (EPI != P7_PLAIN) {
+            const float2 t2 = *reinterpret_cast<const float2*>(A.ex + mrow * (size_t)P + pc2);
+            xv[e][0] = t2.x; xv[e][1] = t2.y;
+        }
+        if (EPI == P7_RESBWD) {
+            const float2 t2 = *reinterpret_cast<const float2*>(A.emask + mrow * (size_t)P + pc2);
+            mk[e][0] = t2.x; mk[e][1] = t2.y;
+        }
+        if (has_add) {
+            const float* pa = A.addend + mrow * (size_t)addP;
+            if (!add_s2) {
+                const float2 t2 = *reinterpret_cast<const float2*>(pa + pc2);
+                adv[e][0] = t2.x; adv[e][1] = t2.y;
+            } else {
+                adv[e][0] = pa[aoff[0]]; adv[e][1] = pa[aoff[1]];
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int tr_off = (8 * q + (r >> 2)) * P6_LD + 4 * (r & 3);
+    auto tr_frag = [&](const __bf16* pln, int s, int h2) -> bf16x8 {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const __bf16* p0 = pln + 32 * s * P6_LD + tr_off + 16 * h2;
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * P6_LD));
+        return cat8_(v0, v1);
+    };
+    auto step = [&](int s, const bf16x8& h, const bf16x8& l) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const bf16x8 bh = tr_frag(Dh, s, h2), bl = tr_frag(Dl, s, h2);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l, bh, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bl, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bh, acc[h2], 0, 0, 0);
+        }
+    };
+    if (mt_ok) {
+        for (int s0 = 0; s0 < kg32; s0 += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (s0 + i < kg32) {
+                    step(s0 + i, ah[i], al[i]);
+                    if (s0 + i + 4 < kg32) fetch_a(s0 + i + 4, ah[i], al[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = mt * 16 + 4 * q + e;
+            const bool mv = m < M;
+            float v[2] = {acc[0][e], acc[1][e]};
+            float s1 = 0.f, s2 = 0.f;
+            if (has_add) { v[0] += av[0] ? adv[e][0] : 0.f; v[1] += av[1] ? adv[e][1] : 0.f; }
+            if (EPI != P7_PLAIN) {
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    const float xj = pv ? xv[e][j2] : 0.f;
+                    if (EPI == P7_RESBWD) v[j2] = (pv && mk[e][j2] > 0.f) ? v[j2] : 0.f;
+                    else v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                    s1 += v[j2];
+                    s2 = fmaf(v[j2], xj, s2);
+                }
+            }
+            if (mv && pv) *reinterpret_cast<float2*>(A.y + ((size_t)n * M + m) * (size_t)P + pl) = make_float2(v[0], v[1]);
+            if (EPI != P7_PLAIN && A.partial != nullptr) {
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
+                if (r == 0 && mv) {
+                    float* pp = A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2;
+                    pp[0] = s1; pp[1] = s2;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // shapes pw6 takes (the caller has checked: dense, packed weights present)
@@ -222,6 +430,52 @@ int x3d_pw6_launch(const float* x, const float* cin, const float* wp, float* y, 
     if (cin) P6_PASS(1); else P6_PASS(0);
 #undef P6_PASS
 #undef P6_GO
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+// ---- data gradient (pw7_kernel): K = Cout, M = Cin
+bool x3d_pw7_ok(int K, int M, int P) {
+    static const bool off = getenv("X3D_NO_PW7") != nullptr;
+    // measured at the base shape: K = 216 -> M = 96 (conv1 of stage 3) is the one layer where the chunked pw5_kernel is
+    // not slower (23.6 vs 24.9 us: six of the eight waves own an M tile, seven k steps of staging for each)
+    if (K > 128 && K < 256 && M <= 96) return false;
+    return !off && getenv("X3D_DGRAD_F32") == nullptr && K >= 64 && K <= P6_RP * P6_MAXPASS && M >= 96 && (P % 4 == 0) && P >= 4;
+}
+
+int x3d_pw7_launch(const float* g, const float* a, const float* cb, const float* wpt, float* out, float* partial, int mode,
+                   const float* ex, const float* emask, const float* ecoef, int e_act, const float* addend,
+                   int addend_stride, int N, int K, int M, int T, int H, int W, hipStream_t s) {
+    P7Args A = {};
+    A.g = g; A.a = a; A.cb = cb; A.wp = wpt; A.y = out; A.partial = partial; A.ex = ex; A.emask = emask; A.ecoef = ecoef;
+    A.e_act = e_act; A.addend = addend; A.addend_stride = addend_stride;
+    A.N = N; A.K = K; A.M = M; A.P = T * H * W; A.tiles = cdiv(A.P, P6_BN); A.T = T; A.H = H; A.W = W;
+    A.Ho = (H - 1) / 2 + 1; A.Wo = (W - 1) / 2 + 1;
+    const int mtiles = cdiv(M, 16);
+    A.mblocks = cdiv(mtiles, 8);
+    A.mt_run = cdiv(mtiles, A.mblocks);
+    const int VT = N * A.tiles;
+    const dim3 grid(cdiv(VT, 8) * 8 * A.mblocks), block(P6_NT);
+    const int kp = cdiv(K, 32) * 32;
+    const size_t lds = (size_t)2 * kp * P6_LD * sizeof(__bf16);
+    const int npass = cdiv(kp, P6_RP);
+#define P7_GO(EPI_, NP)                                                                                             \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP>),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P6_RP * NP * P6_LD * 2);       \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((pw7_kernel<EPI_, NP>), grid, block, lds, s, A);                                          \
+    } while (0)
+#define P7_PASS(EPI_)                                                                                  \
+    do {                                                                                               \
+        if (npass <= 2) P7_GO(EPI_, 2); else if (npass <= 4) P7_GO(EPI_, 4); else P7_GO(EPI_, 7);      \
+    } while (0)
+    if (mode == P7_PLAIN) P7_PASS(P7_PLAIN); else if (mode == P7_ACTBWD) P7_PASS(P7_ACTBWD); else P7_PASS(P7_RESBWD);
+#undef P7_PASS
+#undef P7_GO
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

@@ -30,6 +30,7 @@ SIGNATURES = {
     "x3d_last_error": (ctypes.c_char_p, []),
     "x3d_pw_tiles": (_I, [_I, _I, _I, _I, _I]),
     "x3d_pw_fwd_tiles": (_I, [_I, _I, _I, _I, _I, _I]),
+    "x3d_pw_bwd_tiles": (_I, [_I, _I, _I, _I, _I]),
     "x3d_pw_wants_packed": (_I, [_I, _I]),
     "x3d_pw_pack_floats": (_Z, [_I, _I, _I]),
     "x3d_pw_pack_items": (_Z, [_I, _I, _I]),

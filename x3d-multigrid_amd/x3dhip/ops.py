@@ -93,7 +93,7 @@ def pw_bwd_data(g, a, cb, w, x=None, pre=None, pre_act=ACT_NONE, addend=None, ad
     Cin = w.shape[1]
     o = out if out is not None else _f((N, Cin, T, H, W), g)
     if pre is not None and partial is None:
-        partial = _f((N, Cin, L.x3d_pw_tiles(N, Cout, Cin, T * H * W, 1), 2), g)
+        partial = _f((N, Cin, L.x3d_pw_bwd_tiles(N, Cin, Cout, T * H * W, 1 if wpt is not None else 0), 2), g)
     check(L.x3d_pw_bwd_data(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(wpt), ptr(o), N, Cin, Cout, T, H, W, ptr(x), ptr(pre),
                             pre_act, ptr(addend), addend_stride, ptr(partial) if pre is not None else None,
                             _lib.stream()))
@@ -110,7 +110,7 @@ def pw_bwd_data_res(g, a, cb, w, res_out, res_raw, addend=None, addend_stride=1,
     if tuple(res_out.shape) != (N, Cin, T, H, W) or tuple(res_raw.shape) != (N, Cin, T, H, W):
         raise ValueError("pw_bwd_data_res: res_out / res_raw must be [N, Cin, T, H, W]")
     o = _f((N, Cin, T, H, W), g)
-    partial = _f((N, Cin, L.x3d_pw_tiles(N, Cout, Cin, T * H * W, 1), 2), g)
+    partial = _f((N, Cin, L.x3d_pw_bwd_tiles(N, Cin, Cout, T * H * W, 1 if wpt is not None else 0), 2), g)
     check(L.x3d_pw_bwd_data_res(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(wpt), ptr(o), N, Cin, Cout, T, H, W, ptr(res_out),
                                 ptr(res_raw), ptr(addend), addend_stride, ptr(partial), _lib.stream()))
     return o, partial
