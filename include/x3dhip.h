@@ -307,6 +307,26 @@ int x3d_bn_relu_pool_fwd(const float* a5, const float* c5, float* pooled,
 int x3d_bn_relu_pool_bwd(const float* a5, const float* c5, const float* dpooled,
                          float* g, float* partial, int N, int C, int P, int segs, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Classification head (x3d.py:333-343: fc1 = 1x1x1 conv on the pooled vector without bias, ReLU, Dropout, fc2 = Linear)
+ * and the training script's loss (nn.CrossEntropyLoss, mean over rows: train_x3d_kinetics_multigrid.py:189,259).
+ * R rows = N (task 'class') or N*T (task 'loc'); pooled[R][K], w1[J][K], w2[C][J], b2[C]; J % 4 == 0, K <= 640.
+ * rng = device {seed, draw counter} (two uint64) for the dropout mask (hash of seed, counter, element); x3d_head_ce /
+ * x3d_head_advance_rng advance the counter on the device, so replayed hipGraphs draw fresh masks.
+ * ---------------------------------------------------------------------------------- */
+size_t x3d_head_scratch_floats(int R, int K, int J, int C);
+/* hd[R][J] = dropout(relu(pooled W1^T)) (kept for the backward), logits[R][C] = hd W2^T + b2 */
+int x3d_head_fwd(const float* pooled, const float* w1, const float* w2, const float* b2, float* hd, float* logits,
+                 int R, int K, int J, int C, float p_drop, const unsigned long long* rng, void* stream);
+/* loss[0] = mean_r CE(logits[r], labels[r]); dlogits = d loss / d logits; scratch >= R floats */
+int x3d_head_ce(const float* logits, const long long* labels, float* loss, float* dlogits, float* scratch, int R, int C,
+                unsigned long long* rng, void* stream);
+int x3d_head_advance_rng(unsigned long long* rng, float* dummy1, void* stream);
+/* dW1[J][K], dW2[C][J], db2[C], dpooled[R][K] from dlogits[R][C]; scratch: x3d_head_scratch_floats floats */
+int x3d_head_bwd(const float* dlogits, const float* hd, const float* pooled, const float* w1, const float* w2,
+                 float* dw1, float* dw2, float* db2, float* dpooled, float* scratch, int R, int K, int J, int C,
+                 float p_drop, void* stream);
+
 /* Gradient accumulation over micro-batches (`loss = cls_loss / num_steps_per_update; loss.backward()` repeated
  * num_steps_per_update times before optimizer.step(), train_x3d_kinetics_multigrid.py:119,267-273):
  * acc = (first ? 0 : acc) + scale * g over the flat gradient buffer. */

@@ -493,3 +493,49 @@ def test_dw333_bwd_stats_equals_finalize_then_conv(case):
         assert _rel(out, out_ref) < 1e-5
         assert _rel(dw, dw_ref) < 1e-5
         assert _rel(bp.double().sum(2), bp_ref.double().sum(2)) < 1e-5
+
+
+@pytest.mark.parametrize("R,K,J,C", [(8, 432, 2048, 400), (3, 630, 2048, 157), (20, 432, 2048, 400), (70, 48, 64, 10)])
+def test_head_kernels(R, K, J, C):
+    """csrc/head.hip (fc1 -> ReLU -> Dropout -> fc2, mean cross entropy, and their backward: x3d.py:333-339,
+    train_x3d_kinetics_multigrid.py:189,259) against an fp64 evaluation; with dropout the kernel's own mask (recovered from
+    its output) is fed to the reference, and the mask statistics / per-step redraw are checked."""
+    from x3dhip import ops
+    dev = _dev()
+    pooled = torch.relu(_g(R, K, seed=1))
+    w1 = _g(J, K, seed=2) / np.sqrt(K)
+    w2 = _g(C, J, seed=3) / np.sqrt(J)
+    b2 = 0.1 * _g(C, seed=4)
+    labels = torch.randint(0, C, (R,), generator=torch.Generator().manual_seed(5))
+    to = lambda t: t.float().contiguous().to(dev)
+    for p in (0.0, 0.5):
+        rng = ops.head_rng_state(dev, seed=1234) if p > 0 else None
+        hd, logits = ops.head_fwd(to(pooled), to(w1), to(w2), to(b2), p, rng)
+        h_ref = torch.relu(pooled @ w1.t())
+        if p > 0:
+            mask = (hd.cpu().double() != 0) | (h_ref <= 1e-9)              # kept elements (zeros of the ReLU are undetermined)
+            frac = float(((hd.cpu() != 0) & (h_ref > 1e-3)).sum()) / float((h_ref > 1e-3).sum())
+            assert abs(frac - 0.5) < 0.03, frac
+            hd_ref = h_ref * mask.double() / (1 - p)
+        else:
+            hd_ref = h_ref
+        assert _rel(hd, hd_ref) < TOL
+        lg_ref = (hd_ref @ w2.t() + b2).detach().requires_grad_(True)
+        assert _rel(logits, lg_ref) < TOL
+        loss_ref = F.cross_entropy(lg_ref, labels)
+        loss_ref.backward()
+        loss, dlog = ops.head_ce(logits, labels.to(dev), rng)
+        assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+        assert _rel(dlog, lg_ref.grad) < 1e-4
+        dlg = lg_ref.grad
+        dhd = dlg @ w2
+        dh = dhd * (hd_ref > 0).double() / ((1 - p) if p > 0 else 1.0)
+        dpooled, dw1, dw2, db2 = ops.head_bwd(to(dlg), hd, to(pooled), to(w1), to(w2), p)
+        assert _rel(dw2, dlg.t() @ hd_ref) < TOL
+        assert _rel(db2, dlg.sum(0)) < TOL
+        assert _rel(dw1, dh.t() @ pooled) < TOL
+        assert _rel(dpooled, dh @ w1) < TOL
+        if p > 0:
+            assert int(rng[1]) == 1                                        # head_ce advanced the draw counter
+            hd2, _ = ops.head_fwd(to(pooled), to(w1), to(w2), to(b2), p, rng)
+            assert float(((hd2 != 0) != (hd != 0)).float().mean()) > 0.2   # a fresh mask

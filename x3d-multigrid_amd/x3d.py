@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from x3dhip import engine as _engine
+from x3dhip import ops as _ops
 from x3dhip import _lib as _hiplib
 
 
@@ -292,16 +293,45 @@ class ResNet(nn.Module):
                 pooled = _engine.trunk_forward(self, x, self.training, None)
             if self.training:
                 self._pending_tracked += 1
-        # head (x3d.py:333-343): 1x1x1 conv on the pooled vector(s) == linear; tiny GEMMs
-        w1 = self.fc1.weight.view(self.fc1.weight.shape[0], -1)
+        # head (x3d.py:333-343): 1x1x1 conv on the pooled vector(s) == linear on rows; HIP kernels (csrc/head.hip)
         if self.task == 'loc':
-            # pooled [B, C5, T]: per-frame features -> [B, T, 2048] -> dropout -> fc2 -> [B, n_classes, T]
-            h = F.relu(F.linear(pooled.permute(0, 2, 1), w1))
-            h = self.dropout(h)
-            return self.fc2(h).permute(0, 2, 1)
-        h = F.relu(F.linear(pooled, w1))
-        h = self.dropout(h)
-        return self.fc2(h).unsqueeze(2)
+            # pooled [B, C5, T]: per-frame rows [B*T, C5] -> logits [B*T, n_classes] -> [B, n_classes, T]
+            B, C5, T = pooled.shape
+            rows = pooled.permute(0, 2, 1).reshape(B * T, C5).contiguous()
+            logits = _HeadFunction.apply(self, rows, self.fc1.weight, self.fc2.weight, self.fc2.bias)
+            return logits.view(B, T, -1).permute(0, 2, 1)
+        logits = _HeadFunction.apply(self, pooled, self.fc1.weight, self.fc2.weight, self.fc2.bias)
+        return logits.unsqueeze(2)
+
+    def _head_rng(self, dev):
+        """Device {seed, draw counter} of the head's dropout (created on first use from torch's seed)."""
+        st = getattr(self, "_head_rng_state", None)
+        if st is None or st.device != dev:
+            st = _ops.head_rng_state(dev)
+            self._head_rng_state = st
+        return st
+
+
+class _HeadFunction(torch.autograd.Function):
+    """fc1 -> ReLU -> Dropout -> fc2 (x3d.py:333-339) on the pooled rows, through libx3dhip's head kernels."""
+
+    @staticmethod
+    def forward(ctx, model, pooled, w1, w2, b2):
+        p = float(model.dropout.p) if model.training else 0.0
+        rng = model._head_rng(pooled.device) if p > 0 else None
+        w1v = w1.view(w1.shape[0], -1)
+        hd, logits = _ops.head_fwd(pooled, w1v, w2, b2, p, rng)
+        if rng is not None:
+            _ops.head_advance_rng(rng)          # the next forward draws a fresh dropout mask
+        ctx.save_for_backward(hd, pooled, w1, w2)
+        ctx.p = p
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        hd, pooled, w1, w2 = ctx.saved_tensors
+        dpooled, dw1, dw2, db2 = _ops.head_bwd(dlogits.contiguous().float(), hd, pooled, w1.view(w1.shape[0], -1), w2, ctx.p)
+        return None, dpooled, dw1.view_as(w1), dw2, db2
 
 
 def generate_model(x3d_version, **kwargs):

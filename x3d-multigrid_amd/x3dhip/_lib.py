@@ -73,6 +73,11 @@ SIGNATURES = {
     "x3d_bn_add_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "x3d_bn_relu_pool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "x3d_bn_relu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "x3d_head_scratch_floats": (_Z, [_I, _I, _I, _I]),
+    "x3d_head_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
+    "x3d_head_ce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "x3d_head_advance_rng": (_I, [_P, _P, _P]),
+    "x3d_head_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "x3d_grad_accumulate": (_I, [_P, _P, _Z, _F, _I, _P]),
     "x3d_sgd_fused": (_I, [_P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
 }

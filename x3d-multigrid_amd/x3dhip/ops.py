@@ -472,6 +472,55 @@ def bn_relu_pool_bwd(a5, c5, dpooled, g=None):
     return g, partial
 
 
+# ----------------------------------------------------------------------------- head (fc1 / dropout / fc2 / CE)
+def head_rng_state(dev, seed=None):
+    """Device {seed, draw counter} of the head's dropout (two uint64 kept in an int64 tensor)."""
+    if seed is None:
+        seed = torch.initial_seed()
+    return torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+
+
+def head_fwd(pooled, w1, w2, b2, p_drop=0.0, rng=None):
+    """pooled [R, K] -> (hd [R, J] kept for the backward, logits [R, C])."""
+    _need_cuda(pooled, w1, w2, b2)
+    R, K = pooled.shape
+    J, C = w1.shape[0], w2.shape[0]
+    hd, logits = _f((R, J), pooled), _f((R, C), pooled)
+    check(_lib.lib().x3d_head_fwd(ptr(pooled), ptr(w1), ptr(w2), ptr(b2), ptr(hd), ptr(logits), R, K, J, C, float(p_drop),
+                                  ptr(rng) if p_drop > 0 else None, _lib.stream()))
+    return hd, logits
+
+
+def head_advance_rng(rng):
+    d = _f((1,), rng.new_zeros(1, dtype=torch.float32))
+    check(_lib.lib().x3d_head_advance_rng(ptr(rng), ptr(d), _lib.stream()))
+
+
+def head_ce(logits, labels, rng=None):
+    """Mean cross entropy over the rows of logits [R, C] vs labels [R] (int64): (loss [1], dlogits [R, C])."""
+    _need_cuda(logits)
+    R, C = logits.shape
+    if labels.dtype != torch.int64 or not labels.is_contiguous() or labels.numel() != R:
+        raise ValueError("head_ce: labels must be contiguous int64 [R]")
+    loss, dlog, sc = _f((1,), logits), _f((R, C), logits), _f((R,), logits)
+    check(_lib.lib().x3d_head_ce(ptr(logits), ptr(labels), ptr(loss), ptr(dlog), ptr(sc), R, C, ptr(rng), _lib.stream()))
+    return loss, dlog
+
+
+def head_bwd(dlogits, hd, pooled, w1, w2, p_drop=0.0, outs=None):
+    """(dpooled [R, K], dW1 [J, K], dW2 [C, J], db2 [C]); outs = (dW1, dW2, db2) writes into existing storage."""
+    _need_cuda(dlogits, hd, pooled, w1, w2)
+    L = _lib.lib()
+    R, K = pooled.shape
+    J, C = w1.shape[0], w2.shape[0]
+    dw1, dw2, db2 = outs if outs is not None else (_f((J, K), pooled), _f((C, J), pooled), _f((C,), pooled))
+    dpooled = _f((R, K), pooled)
+    sc = _f((L.x3d_head_scratch_floats(R, K, J, C),), pooled)
+    check(L.x3d_head_bwd(ptr(dlogits), ptr(hd), ptr(pooled), ptr(w1), ptr(w2), ptr(dw1), ptr(dw2), ptr(db2), ptr(dpooled),
+                         ptr(sc), R, K, J, C, float(p_drop), _lib.stream()))
+    return dpooled, dw1, dw2, db2
+
+
 def grad_accumulate(acc, g, scale, first):
     _need_cuda(acc, g)
     check(_lib.lib().x3d_grad_accumulate(ptr(acc), ptr(g), g.numel(), scale, 1 if first else 0, _lib.stream()))

@@ -137,12 +137,38 @@ class Trainer:
         self.param_groups[0]['lr'] = v
 
     # -- pieces ---------------------------------------------------------------------------
+    def _head_loss_bwd(self, pooled, y):
+        """fc1 / ReLU / dropout / fc2, mean cross entropy and their backward on the pooled rows [N, C5], straight into the
+        flat gradient views (x3d.py:333-339, train...:259-271): HIP kernels only, no autograd."""
+        model = self.model
+        p = float(model.dropout.p)
+        rng = model._head_rng(pooled.device) if p > 0 else None
+        w1 = model.fc1.weight
+        w1v = w1.data.view(w1.shape[0], -1)
+        hd, logits = ops.head_fwd(pooled, w1v, model.fc2.weight.data, model.fc2.bias.data, p, rng)
+        loss, dlog = ops.head_ce(logits, y.reshape(-1).contiguous(), rng)
+        dpooled, _, _, _ = ops.head_bwd(dlog, hd, pooled, w1v, model.fc2.weight.data, p,
+                                        outs=(w1.grad.view(w1.shape[0], -1), model.fc2.weight.grad, model.fc2.bias.grad))
+        return loss.view(()), logits.unsqueeze(2), dpooled
+
     def _fwd_bwd(self, x, y):
+        from . import engine
+        model = self.model
+        if getattr(model, "task", "class") != "class" or not model.training or not x.is_cuda:
+            self.fp.grad.zero_()                # generic path through autograd (per-frame head, eval)
+            logits = model(x)
+            loss = F.cross_entropy(logits, y)
+            loss.backward()
+            return loss.detach(), logits.detach()
         self.fp.grad.zero_()
-        logits = self.model(x)
-        loss = F.cross_entropy(logits, y)
-        loss.backward()
-        return loss.detach(), logits.detach()
+        tctx = engine.TrunkContext()
+        with torch.no_grad():
+            pooled = engine.trunk_forward(model, x.contiguous().float(), True, tctx)
+            model._pending_tracked += 1
+            loss, logits, dpooled = self._head_loss_bwd(pooled, y)
+            side = engine.side_stream(x.device) if engine.use_side_stream() else None
+            engine.trunk_backward(model, tctx, dpooled, engine._GradSink(True, side))
+        return loss, logits
 
     def _allreduce(self):
         self.reducer.reduce()
@@ -249,15 +275,11 @@ class Trainer:
         tctx = engine.TrunkContext()
         with torch.no_grad():
             pooled = engine.trunk_forward(model, x.contiguous().float(), True, tctx)
-        pooled = pooled.detach().requires_grad_(True)
-        h = F.relu(F.linear(pooled, model.fc1.weight.view(model.fc1.weight.shape[0], -1)))       # x3d.py:333-339
-        logits = model.fc2(model.dropout(h)).unsqueeze(2)
-        loss = F.cross_entropy(logits, y)
-        loss.backward(inputs=[pooled, model.fc1.weight, model.fc2.weight, model.fc2.bias])       # into the flat .grad views
-        side = engine.side_stream(x.device) if engine.use_side_stream() else None
-        sink = engine._GradSink(True, side)
-        state = engine.trunk_backward(model, tctx, pooled.grad, sink, part="late")
-        return loss.detach(), logits.detach(), tctx, sink, state
+            loss, logits, dpooled = self._head_loss_bwd(pooled, y)                               # x3d.py:333-339
+            side = engine.side_stream(x.device) if engine.use_side_stream() else None
+            sink = engine._GradSink(True, side)
+            state = engine.trunk_backward(model, tctx, dpooled, sink, part="late")
+        return loss, logits, tctx, sink, state
 
     def _capture_split(self, x, y):
         from . import engine
