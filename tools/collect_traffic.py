@@ -39,8 +39,11 @@ def load(d, counter):
 def fam(name):
     """bench.py op family of a kernel name.  Pointwise forward and data-gradient share kernel templates: the input-mode
     template argument tells them apart (IN = 2 is the BN-backward prologue of the data gradient)."""
-    m = re.search(r"pw5_kernel", name)
-    if m:
+    if "pw_bwd_fused_kernel" in name:
+        return "pw_bwd_fused"
+    if "pw6_kernel" in name:
+        return "pw_fwd"
+    if "pw7_kernel" in name or "pw5_kernel" in name:
         return "pw_bwd_data"
     m = re.search(r"pw4_kernel<(\d+)", name) or re.search(r"pw2_kernel<(\d+)", name)
     if m:

@@ -155,6 +155,17 @@ __device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], b
     }
 }
 
+// Value of the previous / next lane of the wave (DPP wave shift; lane 0 / 63 get 0).  The stencil window's two halo
+// columns of a row are the neighbouring threads' float4 ends: fetching them from LDS as scalars (addresses 4 k - 1 and
+// 4 k + 4: stride 4 over 32 banks) was a 4-way bank conflict on two of every three LDS reads -- SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE = 0.72 (forward) / 0.79 (backward) in profiles/r02/a_pmc_sq.txt.
+__device__ __forceinline__ float lane_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));   // wave_shr:1
+}
+__device__ __forceinline__ float lane_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));   // wave_shl:1
+}
+
 __device__ __forceinline__ float dw_act_lo(int act) { return act == X3D_ACT_RELU ? 0.f : -__builtin_inff(); }
 
 // Forward.  LDS holds two planes (double buffer); every thread keeps the values of the three
@@ -278,15 +289,24 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
 
     // LDS offset of this thread's first window element
     const int woff = cc * g.IH * g.WP + (row * STRIDE) * g.WP + DW_PADL + grp * 4 * STRIDE - 1;
+    // stride 1: the halo columns come from the neighbour lanes (same row: consecutive threads); only the first / last lane
+    // of a wave in the middle of a row still reads its one missing element from LDS -- one read per row whose other lanes
+    // fetch a conflict-free dummy word; the first / last group of a row takes the zero padding
+    const int lane_ = tid & 63;
+    const bool g_first = grp == 0, g_last = grp == g.groups - 1;
+    const bool edgeL = lane_ == 0 && !g_first, edgeR = lane_ == 63 && !g_last;
+    const int eoff = edgeL ? woff : (edgeR ? woff + 5 : -1);
     auto read_plane = [&](const float* slot, float (&v)[NV]) {
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const float* rp = slot + woff + kh * g.WP;
             if (STRIDE == 1) {
-                v[kh * 6] = rp[0];
                 const float4 m = *reinterpret_cast<const float4*>(rp + 1);
+                const float e = slot[eoff >= 0 ? eoff + kh * g.WP : (lane_ & 31)];
+                const float lft = lane_prev(m.w), rgt = lane_next(m.x);
+                v[kh * 6] = g_first ? 0.f : (edgeL ? e : lft);
                 v[kh * 6 + 1] = m.x; v[kh * 6 + 2] = m.y; v[kh * 6 + 3] = m.z; v[kh * 6 + 4] = m.w;
-                v[kh * 6 + 5] = rp[5];
+                v[kh * 6 + 5] = g_last ? 0.f : (edgeR ? e : rgt);
             } else {
                 v[kh * 9] = rp[0];
                 const float4 a = *reinterpret_cast<const float4*>(rp + 1);
@@ -552,15 +572,22 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         roff0 = cc * g.IH * g.WP + (hoA - ho_lo) * g.WP + DW_PADL + 2 * grp;
         roff1 = cc * g.IH * g.WP + ((par ? hoB : hoA) - ho_lo) * g.WP + DW_PADL + 2 * grp;
     }
+    // stride 1: halo columns from the neighbour lanes (see lane_prev): the scalar LDS reads were 4-way bank conflicts
+    const int lane_ = tid & 63;
+    const bool g_first = grp == 0, g_last = grp == g.groups - 1;
+    const bool edgeL = lane_ == 0 && !g_first, edgeR = lane_ == 63 && !g_last;
+    const int eoff = edgeL ? roff0 : (edgeR ? roff0 + 5 : -1);
     auto read_plane = [&](const float* slot, float (&v)[NV]) {
         if (STRIDE == 1) {
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const float* rp = slot + roff0 - kh * g.WP;
-                v[kh * 6] = rp[0];
                 const float4 m = *reinterpret_cast<const float4*>(rp + 1);
+                const float e = slot[eoff >= 0 ? eoff - kh * g.WP : (lane_ & 31)];
+                const float lft = lane_prev(m.w), rgt = lane_next(m.x);
+                v[kh * 6] = g_first ? 0.f : (edgeL ? e : lft);
                 v[kh * 6 + 1] = m.x; v[kh * 6 + 2] = m.y; v[kh * 6 + 3] = m.z; v[kh * 6 + 4] = m.w;
-                v[kh * 6 + 5] = rp[5];
+                v[kh * 6 + 5] = g_last ? 0.f : (edgeR ? e : rgt);
             }
         } else {
             const float* ra_ = slot + roff0;
