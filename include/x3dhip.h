@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define X3D_ABI_VERSION 3
+#define X3D_ABI_VERSION 4
 
 #define X3D_OK 0
 #define X3D_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
@@ -326,6 +326,21 @@ int x3d_head_advance_rng(unsigned long long* rng, float* dummy1, void* stream);
 int x3d_head_bwd(const float* dlogits, const float* hd, const float* pooled, const float* w1, const float* w2,
                  float* dw1, float* dw2, float* db2, float* dpooled, float* scratch, int R, int K, int J, int C,
                  float p_drop, void* stream);
+
+/* Charades localisation losses (train_x3d_charades_loc.py:123,168-189) on the per-frame logits [B][C][T] of task 'loc'
+ * (x3d.py:340-343): linear interpolation to the label length TL (F.interpolate, align_corners False), then
+ * losses[0] = cls_loss = BCEWithLogits(max_t, max_t labels), losses[1] = loc_loss = BCEWithLogits(per frame);
+ * dlogits = d[(cls + loc) * grad_scale] / d logits (the script: grad_scale = 1 / (2 num_steps_per_update)).
+ * labels are float [B][C][TL]; scratch >= 2*B*C floats. */
+int x3d_loc_losses(const float* logits, const float* labels, float* losses, float* dlogits, float* scratch, int B, int C,
+                   int T, int TL, float grad_scale, void* stream);
+
+/* Stand-alone SubBatchNorm3d.forward (x3d.py:47-58 used as a module of its own; inside the network the statistics ride in
+ * conv epilogues): x3d_bn_rowstats writes partial[N][C][x3d_ew_tiles(P)][2] = {sum x, sum x^2} (g == NULL) or
+ * {sum g, sum g*x} for x3d_bn_fwd_finalize / x3d_bn_bwd_finalize; x3d_bn_affine applies the per-(sample, channel) map
+ * out = c0*x + c1 (ncoef 2: coef[N][C][2]) or out = c0*g + c1*x + c2 (ncoef 3: the BN backward). */
+int x3d_bn_rowstats(const float* x, const float* g, float* partial, int N, int C, int P, void* stream);
+int x3d_bn_affine(const float* x, const float* g, const float* coef, float* out, int N, int C, int P, int ncoef, void* stream);
 
 /* Gradient accumulation over micro-batches (`loss = cls_loss / num_steps_per_update; loss.backward()` repeated
  * num_steps_per_update times before optimizer.step(), train_x3d_kinetics_multigrid.py:119,267-273):

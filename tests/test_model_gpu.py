@@ -197,3 +197,100 @@ def test_xl_widths_vs_oracle():
     big = [k for k, v in go.items() if v.numel() > 1000]
     med = np.median([float((got[k].double() - go[k].double()).norm() / go[k].double().norm().clamp_min(1e-30)) for k in big])
     assert med < 5e-2
+
+
+def test_standalone_bottleneck_and_subbn_modules():
+    """Bottleneck.forward / SubBatchNorm3d.forward called as modules of their own (x3d.py:47-58, 143-171), forward and
+    backward through autograd, against the fp64 oracle on identical inputs."""
+    import x3d
+    import torch.nn.functional as F
+    dev = _dev()
+    S = 2
+    net = _build("M", S, dev)
+    net.train(True)
+    sd64 = {k: (v.double() if v.is_floating_point() else v)
+            for k, v in synthetic.procedural_state_dict(xo.state_template("M", 400, S), 0).items()}
+    rows = {r[0]: r for r in xo.block_table("M")}
+    g = torch.Generator().manual_seed(11)
+    for name in ("layer2.0", "layer3.1"):
+        p, cin, cm, co, stride, se, ds = rows[name]
+        li, bi = name.split(".")
+        blk = getattr(net, li)[int(bi)]
+        x = torch.relu(torch.randn(4, cin, 4, 20, 20, generator=g, dtype=torch.float64))
+        leaf = {k: v.clone().requires_grad_(True) for k, v in sd64.items() if k.startswith(p + ".") and xo.is_parameter(k)}
+        full = dict(sd64)
+        full.update(leaf)
+        xr = x.clone().requires_grad_(True)
+        out_ref = xo.bottleneck(xr, full, p, stride, se, ds, S, True, None)
+        dout = torch.randn(out_ref.shape, generator=g, dtype=torch.float64)
+        out_ref.backward(dout)
+        xg = x.float().to(dev).requires_grad_(True)
+        for q in blk.parameters():
+            q.grad = None
+        out = blk(xg)                                  # the module's own forward
+        assert parity.rel(out.detach().cpu().numpy(), out_ref.detach().numpy()) < 2e-5
+        out.backward(dout.float().to(dev))
+        assert parity.rel(xg.grad.cpu().numpy(), xr.grad.numpy()) < 3e-3
+        assert parity.rel(blk.conv2.weight.grad.cpu().numpy(), leaf[p + ".conv2.weight"].grad.numpy()) < 3e-3
+        assert parity.rel(blk.bn3.bias.grad.cpu().numpy(), leaf[p + ".bn3.bias"].grad.numpy()) < 3e-3
+    # SubBatchNorm3d on its own: train (split statistics, running-stat update) and eval
+    bn = x3d.SubBatchNorm3d(num_splits=2, num_features=6, affine=True).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, 6))
+        bn.bias.copy_(torch.linspace(-0.2, 0.3, 6))
+    x = torch.randn(4, 6, 3, 9, 7, generator=g, dtype=torch.float64)
+    gy = torch.randn(4, 6, 3, 9, 7, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    w64, b64 = bn.weight.detach().double().cpu().requires_grad_(True), bn.bias.detach().double().cpu().requires_grad_(True)
+    # reference: sample n uses the statistics of split n % S (x3d.py:50-52)
+    ys = []
+    for j in range(2):
+        xs = xr[j::2]
+        m = xs.mean(dim=(0, 2, 3, 4), keepdim=True)
+        v = xs.var(dim=(0, 2, 3, 4), unbiased=False, keepdim=True)
+        ys.append((xs - m) / torch.sqrt(v + 1e-5))
+    yref = torch.empty_like(xr)
+    yref = torch.stack([ys[n % 2][n // 2] for n in range(4)], 0) * w64.view(1, -1, 1, 1, 1) + b64.view(1, -1, 1, 1, 1)
+    yref.backward(gy)
+    xg = x.float().to(dev).requires_grad_(True)
+    bn.train(True)
+    y = bn(xg)
+    y.backward(gy.float().to(dev))
+    assert parity.rel(y.detach().cpu().numpy(), yref.detach().numpy()) < 2e-5
+    assert parity.rel(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
+    assert parity.rel(bn.weight.grad.cpu().numpy(), w64.grad.numpy()) < 1e-4
+    assert parity.rel(bn.bias.grad.cpu().numpy(), b64.grad.numpy()) < 1e-4
+    assert int(bn.split_bn.num_batches_tracked) == 1 and float(bn.split_bn.running_mean.abs().sum()) > 0
+    bn.train(False)
+    bn.aggregate_stats()
+    ye = bn(x.float().to(dev))
+    rm, rv = bn.bn.running_mean.double().cpu(), bn.bn.running_var.double().cpu()
+    yer = (x - rm.view(1, -1, 1, 1, 1)) / torch.sqrt(rv.view(1, -1, 1, 1, 1) + 1e-5) * w64.detach().view(1, -1, 1, 1, 1) \
+        + b64.detach().view(1, -1, 1, 1, 1)
+    assert parity.rel(ye.detach().cpu().numpy(), yer.numpy()) < 2e-5
+
+
+def test_charades_loc_losses_vs_torch():
+    """charades_losses.charades_loc_loss (x3d_loc_losses) against the reference's arithmetic evaluated by torch in fp64
+    (train_x3d_charades_loc.py:123,168-189): F.interpolate(linear) + two BCEWithLogits terms, value and gradient."""
+    import torch.nn.functional as F
+    import charades_losses
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    for (B, C, T, TL, k) in ((3, 157, 16, 64, 1), (2, 7, 5, 13, 2), (2, 5, 8, 8, 1), (1, 3, 9, 4, 1)):
+        z = torch.randn(B, C, T, generator=g, dtype=torch.float64)
+        y = (torch.rand(B, C, TL, generator=g) < 0.2).double()
+        zr = z.clone().requires_grad_(True)
+        zi = F.interpolate(zr, TL, mode="linear")
+        crit = torch.nn.BCEWithLogitsLoss()
+        cls_ref = crit(zi.max(dim=2)[0], y.max(dim=2)[0])
+        loc_ref = crit(zi, y)
+        loss_ref = (cls_ref + loc_ref) / (2 * k)
+        loss_ref.backward()
+        zg = z.float().to(dev).requires_grad_(True)
+        loss, cls, loc = charades_losses.charades_loc_loss(zg, y.float().to(dev), num_steps_per_update=k)
+        loss.backward()
+        assert abs(float(cls) - float(cls_ref)) < 1e-5 * abs(float(cls_ref)) + 1e-7
+        assert abs(float(loc) - float(loc_ref)) < 1e-5 * abs(float(loc_ref)) + 1e-7
+        assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref)) + 1e-7
+        assert parity.rel(zg.grad.cpu().numpy(), zr.grad.numpy()) < 1e-4

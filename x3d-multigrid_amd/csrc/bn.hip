@@ -729,6 +729,41 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const f
     w[i] = wi - lr * mi;
 }
 
+// Stand-alone SubBatchNorm3d (x3d.py:47-58 called as a module of its own): per-(sample, channel) row statistics and the
+// per-row affine map.  g == NULL: partial = {sum x, sum x^2} (forward statistics); else {sum g, sum g*x} (backward).
+__global__ __launch_bounds__(256) void bn_rowstats_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          float* __restrict__ partial, int P, int tiles) {
+    __shared__ float red[4 * 2];
+    const int row = blockIdx.x / tiles, tix = blockIdx.x - row * tiles;
+    const size_t base = (size_t)row * P;
+    const int p0 = tix * EW_TILE;
+    float v[2] = {0.f, 0.f};
+    for (int p = p0 + threadIdx.x; p < min(P, p0 + EW_TILE); p += 256) {
+        const float xv = x[base + p];
+        if (g == nullptr) { v[0] += xv; v[1] = fmaf(xv, xv, v[1]); }
+        else { const float gv = g[base + p]; v[0] += gv; v[1] = fmaf(gv, xv, v[1]); }
+    }
+    float o[2];
+    block_sum_256<2>(v, red, o);
+    if (threadIdx.x == 0) {
+        partial[((size_t)row * tiles + tix) * 2] = o[0];
+        partial[((size_t)row * tiles + tix) * 2 + 1] = o[1];
+    }
+}
+
+// ncoef 2: out = c0 * x + c1;  ncoef 3: out = c0 * g + c1 * x + c2   (coef per (sample, channel) row)
+__global__ __launch_bounds__(256) void bn_affine_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ coef, float* __restrict__ out, int P,
+                                                        int tiles, int ncoef) {
+    const int row = blockIdx.x / tiles, tix = blockIdx.x - row * tiles;
+    const size_t base = (size_t)row * P;
+    const int p0 = tix * EW_TILE;
+    const float c0 = coef[(size_t)row * ncoef], c1 = coef[(size_t)row * ncoef + 1];
+    const float c2 = ncoef == 3 ? coef[(size_t)row * 3 + 2] : 0.f;
+    for (int p = p0 + threadIdx.x; p < min(P, p0 + EW_TILE); p += 256)
+        out[base + p] = ncoef == 3 ? fmaf(c0, g[base + p], fmaf(c1, x[base + p], c2)) : fmaf(c0, x[base + p], c1);
+}
+
 // acc = (first ? 0 : acc) + scale * g  (gradient accumulation over micro-batches: loss / num_steps_per_update,
 // train_x3d_kinetics_multigrid.py:267-273)
 __global__ __launch_bounds__(256) void grad_accumulate_kernel(float* __restrict__ acc, const float* __restrict__ g, size_t n,
@@ -901,6 +936,27 @@ extern "C" int x3d_bn_relu_pool_bwd(const float* a5, const float* c5, const floa
     X3D_CHECK_ARG((long long)N * C * tiles <= 0x7fffffffLL);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel, dim3((unsigned)(N * C * tiles)), dim3(256), 0, (hipStream_t)stream, a5, c5, dpooled,
                        g, partial, P, tiles, segs);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_bn_rowstats(const float* x, const float* g, float* partial, int N, int C, int P, void* stream) {
+    X3D_CHECK_ARG(x && partial && N > 0 && C > 0 && P > 0);
+    const int tiles = cdiv(P, EW_TILE);
+    X3D_CHECK_ARG((long long)N * C * tiles <= 0x7fffffffLL);
+    hipLaunchKernelGGL(bn_rowstats_kernel, dim3((unsigned)(N * C * tiles)), dim3(256), 0, (hipStream_t)stream, x, g, partial, P,
+                       tiles);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+extern "C" int x3d_bn_affine(const float* x, const float* g, const float* coef, float* out, int N, int C, int P, int ncoef,
+                             void* stream) {
+    X3D_CHECK_ARG(x && coef && out && N > 0 && C > 0 && P > 0 && (ncoef == 2 || (ncoef == 3 && g != nullptr)));
+    const int tiles = cdiv(P, EW_TILE);
+    X3D_CHECK_ARG((long long)N * C * tiles <= 0x7fffffffLL);
+    hipLaunchKernelGGL(bn_affine_kernel, dim3((unsigned)(N * C * tiles)), dim3(256), 0, (hipStream_t)stream, x, g, coef, out, P,
+                       tiles, ncoef);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

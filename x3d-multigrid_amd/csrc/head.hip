@@ -284,7 +284,78 @@ __global__ __launch_bounds__(256) void head_sum_slices_kernel(const float* __res
     out[i] = s;
 }
 
+// Charades localisation losses (train_x3d_charades_loc.py:123,168-189): per-frame logits [B][C][T] are linearly interpolated
+// to the label length TL (F.interpolate(mode='linear'), align_corners False), then
+//   loc_loss = BCEWithLogits(interp, labels)                      (mean over B*C*TL)
+//   cls_loss = BCEWithLogits(max_t interp, max_t labels)          (mean over B*C)
+//   loss     = (cls_loss + loc_loss) / (2 * num_steps_per_update)
+// One thread per (b, c) row: forward sums and the gradient w.r.t. the un-interpolated logits (scatter of two taps per frame).
+__device__ __forceinline__ float bce_logits(float z, float y) { return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z))); }
+
+__global__ __launch_bounds__(256) void loc_loss_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                       float* __restrict__ dlogits, float* __restrict__ rowsum, int rows, int T,
+                                                       int TL, float gscale) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const float* z = logits + (size_t)row * T;
+    const float* y = labels + (size_t)row * TL;
+    float* dz = dlogits + (size_t)row * T;
+    for (int t = 0; t < T; ++t) dz[t] = 0.f;
+    const float scale = (float)T / (float)TL;
+    const float gl = gscale / ((float)rows * (float)TL), gc = gscale / (float)rows;
+    float loc = 0.f, zmax = -__builtin_inff(), ymax = -__builtin_inff();
+    int imax0 = 0, imax1 = 0;
+    float lmax = 0.f;
+    for (int i = 0; i < TL; ++i) {
+        float src = scale * ((float)i + 0.5f) - 0.5f;
+        src = src < 0.f ? 0.f : src;
+        const int i0 = min((int)src, T - 1), i1 = i0 + (i0 < T - 1 ? 1 : 0);
+        const float l1 = src - (float)i0, l0 = 1.f - l1;
+        const float zi = l0 * z[i0] + l1 * z[i1];
+        loc += bce_logits(zi, y[i]);
+        const float d = (1.f / (1.f + expf(-zi)) - y[i]) * gl;
+        dz[i0] += l0 * d;
+        dz[i1] += l1 * d;
+        if (zi > zmax) { zmax = zi; imax0 = i0; imax1 = i1; lmax = l1; }
+        ymax = fmaxf(ymax, y[i]);
+    }
+    const float dc = (1.f / (1.f + expf(-zmax)) - ymax) * gc;
+    dz[imax0] += (1.f - lmax) * dc;
+    dz[imax1] += lmax * dc;
+    rowsum[(size_t)row * 2] = bce_logits(zmax, ymax);
+    rowsum[(size_t)row * 2 + 1] = loc;
+}
+
+// out[0] = mean over rows of rowsum[.][0]; out[1] = sum of rowsum[.][1] / (rows * TL)
+__global__ __launch_bounds__(256) void loc_loss_reduce_kernel(const float* __restrict__ rowsum, int rows, int TL,
+                                                              float* __restrict__ out) {
+    __shared__ double red[4][2];
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < rows; i += 256) { s0 += (double)rowsum[(size_t)i * 2]; s1 += (double)rowsum[(size_t)i * 2 + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s0; red[threadIdx.x >> 6][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (float)(((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) / (double)rows);
+        out[1] = (float)(((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])) / ((double)rows * (double)TL));
+    }
+}
+
 }  // namespace
+
+// losses[0] = cls_loss, losses[1] = loc_loss; dlogits = d[(cls + loc) * grad_scale] / d logits (the script uses
+// grad_scale = 1 / (2 * num_steps_per_update)); scratch: 2 * B * C floats.
+extern "C" int x3d_loc_losses(const float* logits, const float* labels, float* losses, float* dlogits, float* scratch, int B,
+                              int C, int T, int TL, float grad_scale, void* stream) {
+    X3D_CHECK_ARG(logits && labels && losses && dlogits && scratch && B > 0 && C > 0 && T > 0 && TL > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = B * C;
+    hipLaunchKernelGGL(loc_loss_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, logits, labels, dlogits, scratch, rows, T, TL,
+                       grad_scale);
+    hipLaunchKernelGGL(loc_loss_reduce_kernel, dim3(1), dim3(256), 0, s, scratch, rows, TL, losses);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
 
 extern "C" size_t x3d_head_scratch_floats(int R, int K, int J, int C) {
     (void)C;

@@ -111,8 +111,77 @@ class SubBatchNorm3d(nn.Module):
         self.bn.running_var.data = (var.sum(0) / S + ((mu - mean) ** 2).sum(0) / S).detach()
 
     def forward(self, x):
-        raise NotImplementedError("SubBatchNorm3d is fused into the neighbouring HIP conv kernels; "
-                                  "call the enclosing ResNet")
+        """Stand-alone use (x3d.py:47-58).  Inside ResNet the statistics ride in the producing conv's epilogue and the
+        normalisation in the consumer's load; called as a module of its own it is two row passes over the HIP kernels."""
+        if not x.is_cuda:
+            raise _hiplib.X3DHipError("SubBatchNorm3d.forward needs a CUDA(HIP) tensor (no CPU path)")
+        return _SubBNFunction.apply(self, x.contiguous().float(), self.weight, self.bias)
+
+
+class _SubBNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, weight, bias):
+        N, C = x.shape[:2]
+        P = x[0, 0].numel()
+        S = mod.num_splits
+        if mod.training:
+            if N % S != 0:
+                raise ValueError("batch size %d is not divisible by num_splits %d (x3d.py:50)" % (N, S))
+            coef, save, _ = _ops.bn_fwd_finalize(_ops.bn_rowstats(x), S, P, weight.data, bias.data,
+                                                 mod.split_bn.running_mean, mod.split_bn.running_var,
+                                                 _engine.BN_MOMENTUM, _engine.BN_EPS)
+            mod.split_bn.num_batches_tracked += 1
+            ctx.save_for_backward(x, save, weight)
+            ctx.S, ctx.P = S, P
+        else:
+            coef = _ops.bn_eval_coef(mod.bn.running_mean, mod.bn.running_var, weight.data, bias.data, N, _engine.BN_EPS)
+            ctx.save_for_backward(coef)
+            ctx.S = 0
+        return _ops.bn_affine(x, coef)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().float()
+        if ctx.S == 0:                  # eval: y = c0 * x + c1 with constant statistics
+            (coef,) = ctx.saved_tensors
+            c0 = coef[..., 0].contiguous()
+            dx = g * c0.view(c0.shape[0], c0.shape[1], *([1] * (g.dim() - 2)))
+            return None, dx, None, None
+        x, save, weight = ctx.saved_tensors
+        cb, dgamma, dbeta = _ops.bn_bwd_finalize(_ops.bn_rowstats(x, g), ctx.S, ctx.P, weight.data, save)
+        return None, _ops.bn_affine(x, cb, g), dgamma, dbeta
+
+
+class _BlockPacks:
+    """Packed weights of one block, built on demand (ResNet keeps one batched pack for the whole model instead)."""
+
+    def get(self, w, transposed=False):
+        return _ops.pw_pack(w.data.view(w.shape[0], -1), transposed=transposed)
+
+
+class _BlockFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, blk, x, *params):
+        S = blk.bn1.num_splits
+        if blk.training and x.shape[0] % S != 0:
+            raise ValueError("batch size %d is not divisible by num_splits %d (x3d.py:50)" % (x.shape[0], S))
+        tctx = _engine.TrunkContext()
+        out, _ = _engine._block_forward(blk, x, None, S, blk.training, tctx if blk.training else None, _BlockPacks())
+        if blk.training:
+            for m in (blk.bn1, blk.bn2, blk.bn3) + ((blk.downsample[1],) if blk.downsample is not None else ()):
+                m.split_bn.num_batches_tracked += 1
+        ctx.blk, ctx.tctx, ctx.params = blk, tctx, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.blk.training:
+            raise RuntimeError("Bottleneck.forward in eval mode is inference only")
+        sink = _engine._GradSink(False)
+        dprev, _ = _engine._block_backward(ctx.tctx.blocks[0], dout.contiguous().float(), sink)
+        sink.flush()
+        ctx.tctx = None
+        return (None, dprev) + tuple(sink.written[p].view(p.shape) for p in ctx.params)
 
 
 class SwishEfficient(torch.autograd.Function):
@@ -174,7 +243,10 @@ class Bottleneck(nn.Module):
         return int(width_out)
 
     def forward(self, x):
-        raise NotImplementedError("Bottleneck runs inside ResNet.forward (fused HIP schedule)")
+        """Stand-alone use (x3d.py:143-171): the same fused HIP schedule ResNet.forward runs per block."""
+        if not x.is_cuda:
+            raise _hiplib.X3DHipError("Bottleneck.forward needs a CUDA(HIP) tensor (no CPU path)")
+        return _BlockFunction.apply(self, x.contiguous().float(), *[p for p in self.parameters()])
 
 
 _PLANES = {"S": [(54, 24), (108, 48), (216, 96), (432, 192)],

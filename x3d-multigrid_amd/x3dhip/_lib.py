@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx3dhip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 
@@ -78,6 +78,9 @@ SIGNATURES = {
     "x3d_head_ce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "x3d_head_advance_rng": (_I, [_P, _P, _P]),
     "x3d_head_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "x3d_loc_losses": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "x3d_bn_rowstats": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "x3d_bn_affine": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "x3d_grad_accumulate": (_I, [_P, _P, _Z, _F, _I, _P]),
     "x3d_sgd_fused": (_I, [_P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
 }

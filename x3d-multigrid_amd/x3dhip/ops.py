@@ -521,6 +521,37 @@ def head_bwd(dlogits, hd, pooled, w1, w2, p_drop=0.0, outs=None):
     return dpooled, dw1, dw2, db2
 
 
+def loc_losses(logits, labels, grad_scale=0.5):
+    """Charades localisation losses on per-frame logits [B, C, T] vs float labels [B, C, TL]:
+    (losses [2] = (cls_loss, loc_loss), dlogits [B, C, T] of (cls + loc) * grad_scale)."""
+    _need_cuda(logits, labels)
+    B, C, T = logits.shape
+    TL = labels.shape[2]
+    losses, dlog, sc = _f((2,), logits), _f((B, C, T), logits), _f((2 * B * C,), logits)
+    check(_lib.lib().x3d_loc_losses(ptr(logits), ptr(labels), ptr(losses), ptr(dlog), ptr(sc), B, C, T, TL, float(grad_scale),
+                                    _lib.stream()))
+    return losses, dlog
+
+
+def bn_rowstats(x, g=None):
+    _need_cuda(x, g)
+    L = _lib.lib()
+    N, C = x.shape[:2]
+    P = x[0, 0].numel()
+    partial = _f((N, C, L.x3d_ew_tiles(P), 2), x)
+    check(L.x3d_bn_rowstats(ptr(x), ptr(g), ptr(partial), N, C, P, _lib.stream()))
+    return partial
+
+
+def bn_affine(x, coef, g=None):
+    _need_cuda(x, coef, g)
+    N, C = x.shape[:2]
+    P = x[0, 0].numel()
+    out = _f(x.shape, x)
+    check(_lib.lib().x3d_bn_affine(ptr(x), ptr(g), ptr(coef), ptr(out), N, C, P, coef.shape[-1], _lib.stream()))
+    return out
+
+
 def grad_accumulate(acc, g, scale, first):
     _need_cuda(acc, g)
     check(_lib.lib().x3d_grad_accumulate(ptr(acc), ptr(g), g.numel(), scale, 1 if first else 0, _lib.stream()))
