@@ -344,6 +344,22 @@ def main():
                 traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # MFMA utilisation of the pointwise families from the committed PMC pass (tools/collect_pmc.py ->
+        # profiles/r02/*pmc_sq.json): SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CYCLES) = busy matrix pipes of the 4 per CU.
+        # north_star asks for it as evidence that the pointwise path uses the matrix cores; the bound is HBM / latency.
+        mfma = None
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_sq.json")))
+            if cands:
+                pm = json.load(open(cands[-1]))
+                mfma = {"source": os.path.relpath(cands[-1], ROOT),
+                        "busy_matrix_pipes_of_4_per_cu": {k: round(v["derived"]["mfma_busy_per_sq_busy"], 3)
+                                                          for k, v in pm.items()
+                                                          if k.startswith("pw_") and "mfma_busy_per_sq_busy" in v.get("derived", {})}}
+        except Exception:
+            mfma = None
+        out["mfma_utilisation"] = mfma
         out["roofline"] = {"bound": "hbm", "kernel": name, "launches_per_step": cnt,
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -48,9 +48,11 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
     floor = abs(float(g["grad_global_norm"]) - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"])
     rep["global_norm_err"] = abs(gg - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"])
     rep["global_norm_floor"] = floor
-    # the global norm averages the per-element rounding noise out (floor <= 4.6e-4 in every fixture): BASELINE's plain
-    # 1e-3, no noise-floor allowance
-    assert rep["global_norm_err"] < rtol, rep
+    # the global norm averages the per-element rounding noise out (floor <= 4.6e-4 in every X3D-M fixture): BASELINE's
+    # plain 1e-3, no noise-floor allowance.  Only where the reference's OWN fp32 run is further than rtol / 2 from its fp64
+    # value (the tiny-clip XL fixture: 1600 tensors at B = 2, floor 4.8e-3) is the floor term admitted.
+    bound = rtol if floor < 0.5 * rtol else rtol + 3 * floor
+    assert rep["global_norm_err"] < bound, rep
     # per-parameter norms
     scale = n64 + 1e-6 * float(g["grad_global_norm64"])
     e_got = np.abs(got - n64) / scale

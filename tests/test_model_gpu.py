@@ -39,12 +39,12 @@ TRAIN_CASES = ["train_M_2x4x32_s1", "train_M_8x4x64_s2", "train_M_16x2x47_s4", "
                "train_M_64x4x112_s8", "train_M_16x16x224_s2"]
 
 
-@pytest.mark.parametrize("case", TRAIN_CASES)
+@pytest.mark.parametrize("case", TRAIN_CASES + ["train_XL_2x4x64_s1"])        # + X3D-XL widths, pinned by the reference
 def test_train_step_vs_reference_golden(golden_dir, case):
     dev = _dev()
     g = _golden(golden_dir, case)
     B, T, H, S = [int(v) for v in g["shape"]]
-    net = _build("M", S, dev, int(g["seed"][0]))
+    net = _build(case.split("_")[1], S, dev, int(g["seed"][0]))
     net.train(True)
     x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1])).to(dev)
     y = synthetic.synthetic_labels(B, seed=int(g["seed"][1])).to(dev)

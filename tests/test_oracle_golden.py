@@ -37,15 +37,17 @@ def test_state_dict_keys_match_reference(golden_dir):
 
 
 @pytest.mark.parametrize("case", ["train_M_2x4x32_s1", "train_M_8x4x64_s2", "train_M_16x2x47_s4",
-                                  "train_M_2x4x111_s1", "train_M_2x4x158_s2", "train_M_2x8x112_s1"])
+                                  "train_M_2x4x111_s1", "train_M_2x4x158_s2", "train_M_2x8x112_s1",
+                                  "train_XL_2x4x64_s1"])          # XL widths (x3d.py:355) pinned by the reference itself
 def test_train_step_matches_reference(golden_dir, case):
     g = _load(golden_dir, case)
     B, T, H, S = [int(v) for v in g["shape"]]
+    ver = case.split("_")[1]
     torch.set_num_threads(8)
-    sd = synthetic.procedural_state_dict(xo.state_template("M", 400, S), int(g["seed"][0]))
+    sd = synthetic.procedural_state_dict(xo.state_template(ver, 400, S), int(g["seed"][0]))
     x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1]))
     y = synthetic.synthetic_labels(B, seed=int(g["seed"][1]))
-    logits, loss, grads, new_stats = xo.train_step_grads(x, y, sd, "M", S)
+    logits, loss, grads, new_stats = xo.train_step_grads(x, y, sd, ver, S)
     parity.check_forward(logits[:, :, 0].numpy(), loss.item(), g, rtol=RTOL)
     parity.check_grads({k: v.numpy() for k, v in grads.items()}, g, synthetic.gradient_sketch)
     parity.check_bn_stats({k: v.numpy() for k, v in new_stats.items() if v.ndim}, g, rtol=RTOL)
@@ -61,7 +63,7 @@ def test_train_step_matches_reference(golden_dir, case):
             assert _rel(agg[k[7:] + ".bn.running_var"].numpy(), g[k]) < RTOL, k
     sd2.update(agg)
     with torch.no_grad():
-        ev = xo.forward(x, sd2, "M", S, training=False)
+        ev = xo.forward(x, sd2, ver, S, training=False)
     assert _rel(ev[:, :, 0].numpy(), g["eval_logits"]) < RTOL
 
 
