@@ -127,6 +127,11 @@ _DW_BWD_STATS = os.environ.get("X3D_DW_BWD_STATS", "1") == "1"
 _NO_RES_FUSE = os.environ.get("X3D_NO_RES_FUSE", "0") == "1"
 _NO_BATCH_REDUCE = os.environ.get("X3D_NO_BATCH_REDUCE", "0") == "1"
 _NO_FUSED_BWD = os.environ.get("X3D_NO_FUSED_BWD", "0") == "1"
+# X3D_WGRAD_OVERLAP=1: the postponed weight gradients of layer4 / layer3 are launched on a second stream when their stage's
+# data-gradient chain is done, beside the NEXT stage's chain.  OFF by default: measured 8.89 vs 8.59 ms per step in round 2
+# (two forks per replay; co-running kernels slow the latency-bound chain by more than the overlap hides -- the same
+# result as round 1's per-conv side stream)
+_WGRAD_OVERLAP = os.environ.get("X3D_WGRAD_OVERLAP", "0") == "1"
 
 
 def _fused_bwd(grads, g, x, mode=0, has_addend=False):
@@ -274,6 +279,29 @@ class _GradSink:
     def flush(self):
         if self.deferred is not None:
             self.deferred.flush()
+        self.join()
+
+    def flush_async(self, device):
+        """Launch what has been postponed so far on the second stream (fork here, join in flush()).  Every tensor the
+        launches read or write stays referenced until the join."""
+        d = self.deferred
+        if d is None or not _WGRAD_OVERLAP or self.side is not None or (not d.wjobs and not d.reduces):
+            return
+        main = torch.cuda.current_stream()
+        st = side_stream(device)
+        st.wait_stream(main)
+        self._async_keep = getattr(self, "_async_keep", [])
+        self._async_keep.append((d.keep, list(d.reduces)))
+        with torch.cuda.stream(st):
+            d.flush()
+        self._async_side = st
+
+    def join(self):
+        st = getattr(self, "_async_side", None)
+        if st is not None:
+            torch.cuda.current_stream().wait_stream(st)
+            self._async_side = None
+            self._async_keep = []
 
     def out(self, p):
         if self.direct and p.grad is not None:
@@ -311,8 +339,11 @@ def trunk_backward(model, ctx, dpooled, grads, part="all", state=None):
         del g5
         pstem = None
         last = len(blocks) if part == "all" else n_late
+        n4 = len(model.layer4)
         for i in range(last):
             dcur, pstem = _block_backward(blocks[i], dcur, grads, blocks[i + 1] if i + 1 < len(blocks) else None)
+            if i + 1 == n4 or (i + 1 == n_late and part == "all"):
+                grads.flush_async(dcur[0].device if isinstance(dcur, tuple) else dcur.device)
         if part == "late":
             grads.flush()
             if grads.side is not None:
