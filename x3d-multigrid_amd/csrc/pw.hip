@@ -2109,6 +2109,154 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
             }
 }
 
+// Wide-tile form for the large-channel layers (stages 3-4, conv5; dense input): 8 waves, a (256 x 96) or (128 x 224) block
+// of dW per workgroup, so that a stage-3 weight (216 x 96 / 96 x 216) is ONE block and every voxel chunk is staged once
+// instead of once per 128 x 64 block (4 blocks at stage 3, 12 at stage 4: the batched launches fetched 2.2x their
+// algorithmic bytes, profiles/r02/a_traffic.json, and split the same values four times).  Waves form a 4 (dY) x 2 (input)
+// grid: MW x NW sixteen-row tiles per wave keep the LDS fragment reads per MFMA at the 128 x 64 kernel's level.
+template <int CO, int CI>
+__device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, const int blk) {
+    constexpr int NT = 512, RP = NT / 16;                // 32 rows staged per pass
+    constexpr int ND = CO / RP, NX = CI / RP;
+    constexpr int WCO = 4, WCI = 2;
+    constexpr int MW = CO / 16 / WCO, NW = CI / 16 / WCI;
+    static_assert(CO % (16 * WCO) == 0 && CI % (16 * WCI) == 0 && CO % RP == 0 && CI % RP == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) __bf16 wl4[];
+    __bf16* Dh = wl4;
+    __bf16* Dlo = Dh + CO * W3_LD;
+    __bf16* Xh = Dlo + CO * W3_LD;
+    __bf16* Xlo = Xh + CI * W3_LD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int co0 = (blk / A.cib) * CO, ci0 = (blk % A.cib) * CI;
+    const int P = A.P;
+    const int cps = (P + W2_PT - 1) / W2_PT;
+    const int total = A.N * cps;
+    const int c4 = (tid & 15) * 4;
+    const int row0 = tid >> 4;
+
+    float4 rg[ND], ra[ND], rx[NX];
+    float k0[ND], k1[ND], k2[ND], sc[NX], sh[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+
+    auto fetch = [&](int c) {
+        const int n = c / cps, pt = (c - n * cps) * W2_PT;
+        const int pc = min(pt + c4, P - 4);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int co = min(co0 + row0 + RP * i, A.Co - 1);
+            const size_t base = ((size_t)n * A.Co + co) * (size_t)P + pc;
+            rg[i] = *reinterpret_cast<const float4*>(A.g + base);
+            ra[i] = *reinterpret_cast<const float4*>(A.a + base);
+            const float* cb = A.cb + ((size_t)n * A.Co + co) * 3;
+            k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int ci = min(ci0 + row0 + RP * i, A.Ci - 1);
+            rx[i] = *reinterpret_cast<const float4*>(A.x + ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc);
+            if (A.pre != nullptr) {
+                const float2 p2 = *reinterpret_cast<const float2*>(A.pre + ((size_t)n * A.Ci + ci) * 2);
+                sc[i] = p2.x; sh[i] = p2.y;
+            }
+        }
+    };
+    auto store = [&](int c) {
+        const int n = c / cps, pt = (c - n * cps) * W2_PT;
+        (void)n;
+        const bool pvv = pt + c4 < P;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const bool ok = pvv && (co0 + row0 + RP * i < A.Co);
+            const float gv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w}, av[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
+            bf16x4 hi, lo;
+            split_bf16x4(v, hi, lo);
+            *reinterpret_cast<bf16x4*>(&Dh[(row0 + RP * i) * W3_LD + c4]) = hi;
+            *reinterpret_cast<bf16x4*>(&Dlo[(row0 + RP * i) * W3_LD + c4]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const bool ok = pvv && (ci0 + row0 + RP * i < A.Ci);
+            float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+            if (A.pre != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(sc[i], v[e], sh[i]), A.pre_act);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            bf16x4 hi, lo;
+            split_bf16x4(v, hi, lo);
+            *reinterpret_cast<bf16x4*>(&Xh[(row0 + RP * i) * W3_LD + c4]) = hi;
+            *reinterpret_cast<bf16x4*>(&Xlo[(row0 + RP * i) * W3_LD + c4]) = lo;
+        }
+    };
+
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wco0 = MW * (wave % WCO), wci0 = NW * (wave / WCO);
+
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < W2_PT / 32; ++s) {
+            bf16x8 ah[MW], al[MW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                const int off = ((wco0 + i) * 16 + r) * W3_LD + s * 32 + 8 * q;
+                ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
+                al[i] = *reinterpret_cast<const bf16x8*>(&Dlo[off]);
+            }
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int off = ((wci0 + j) * 16 + r) * W3_LD + s * 32 + 8 * q;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Xh[off]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    int c = grp;
+    if (c < total) {
+        fetch(c);
+        store(c);
+        __syncthreads();
+        for (; c < total; c += A.groups) {
+            const int cn = c + A.groups;
+            if (cn < total) fetch(cn);
+            compute();
+            __syncthreads();
+            if (cn < total) { store(cn); __syncthreads(); }
+        }
+    }
+    float* out = A.wpartial + (size_t)grp * A.Co * A.Ci;
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int oc = co0 + (wco0 + i) * 16 + 4 * q + e, ic = ci0 + (wci0 + j) * 16 + r;
+                if (oc < A.Co && ic < A.Ci) out[(size_t)oc * A.Ci + ic] = acc[i][j][e];
+            }
+}
+
+struct WgBatch;
+template <int CO, int CI>
+__global__ __launch_bounds__(512, 2) void pw_wgrad4_batch_kernel(const WgBatch B);
+
 template <int CO, int CI, bool GATHER>
 __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
     wgrad3_body<CO, CI, GATHER>(A, blockIdx.x, blockIdx.y);
@@ -2126,6 +2274,15 @@ struct WgBatch {
     int njobs;
 };
 
+template <int CO, int CI>
+__global__ __launch_bounds__(512, 2) void pw_wgrad4_batch_kernel(const WgBatch B) {
+    int j = 0;
+    while (j + 1 < B.njobs && (int)blockIdx.x >= B.wg0[j + 1]) ++j;
+    const int local = (int)blockIdx.x - B.wg0[j];
+    const int groups = B.job[j].groups;
+    wgrad4_body<CO, CI>(B.job[j], local % groups, local / groups);
+}
+
 template <int CO, int CI, bool GATHER>
 __global__ __launch_bounds__(256, 2) void pw_wgrad3_batch_kernel(const WgBatch B) {
     int j = 0;
@@ -2142,6 +2299,14 @@ static bool wgrad2_ok(int P, long long Pin, int Co, int Ci, bool strided) {
 // workgroup tile of the split-bf16 kernel for a Co x Ci weight
 static int wg3_co(int Co) { return Co > 64 ? 128 : 64; }
 static int wg3_ci(int Ci) { return Ci > 32 ? 64 : 32; }
+// wide tiles (wgrad4_body, batched launches only): 1 = 256 x 96 (many dY channels), 2 = 128 x 224 (many input channels)
+static int wg4_kind(int Co, int Ci, bool dense) {
+    static const bool off = getenv("X3D_NO_WGRAD4") != nullptr;
+    if (off || !dense) return 0;
+    if (Co > 128 && Ci > 64) return Co >= Ci ? 1 : 2;
+    if (Co > 64 && Ci > 128) return 2;
+    return 0;
+}
 
 // tiled = 1: pw_wgrad2_kernel (cob x cib blocks of 128 x 64), else the direct-load kernel
 static void wgrad_plan(int N, int P, int Co, int Ci, bool dense, int* tiled, int* groups, int* cob, int* cib,
@@ -2442,12 +2607,27 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
     hipStream_t s = (hipStream_t)stream;
     const bool f32 = getenv("X3D_WGRAD_F32") != nullptr;
     // variant id: bit 0 = CI 64, bit 1 = CO 128, bit 2 = gathered (strided) input; -1 = not a wgrad3 shape
-    static thread_local WgBatch B[8];
-    for (int v = 0; v < 8; ++v) { B[v].njobs = 0; B[v].wg0[0] = 0; }
+    static thread_local WgBatch B[10];
+    for (int v = 0; v < 10; ++v) { B[v].njobs = 0; B[v].wg0[0] = 0; }
     auto launch = [&](int v) -> int {
         WgBatch& b = B[v];
         if (b.njobs == 0) return X3D_OK;
         const dim3 grid(b.wg0[b.njobs]), block(256);
+        if (v >= 8) {               // wide tiles: 8 waves, dynamic LDS (two planes of dY and of the input)
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<256, 96>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 96) * W3_LD * 2);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<128, 224>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 224) * W3_LD * 2);
+                attr_done = true;
+            }
+            if (v == 8) hipLaunchKernelGGL((pw_wgrad4_batch_kernel<256, 96>), grid, dim3(512), 2 * (256 + 96) * W3_LD * 2, s, b);
+            else hipLaunchKernelGGL((pw_wgrad4_batch_kernel<128, 224>), grid, dim3(512), 2 * (128 + 224) * W3_LD * 2, s, b);
+            b.njobs = 0;
+            X3D_LAUNCH_CHECK();
+            return X3D_OK;
+        }
         switch (v) {
             case 0: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 32, false>), grid, block, 0, s, b); break;
             case 1: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 64, false>), grid, block, 0, s, b); break;
@@ -2482,7 +2662,13 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
             if (rc != X3D_OK) return rc;
             continue;
         }
-        const int v = (wg3_ci(J.Cin) == 64 ? 1 : 0) | (wg3_co(J.Cout) == 128 ? 2 : 0) | (A.strided ? 4 : 0);
+        int v = (wg3_ci(J.Cin) == 64 ? 1 : 0) | (wg3_co(J.Cout) == 128 ? 2 : 0) | (A.strided ? 4 : 0);
+        const int wide = wg4_kind(J.Cout, J.Cin, !A.strided);
+        if (wide) {                // same voxel groups (wpartial is sized by them), fewer and wider channel blocks
+            v = 7 + wide;
+            A.cob = cdiv(J.Cout, wide == 1 ? 256 : 128);
+            A.cib = cdiv(J.Cin, wide == 1 ? 96 : 224);
+        }
         WgBatch& b = B[v];
         b.job[b.njobs] = A;
         b.wg0[b.njobs + 1] = b.wg0[b.njobs] + A.groups * A.cob * A.cib;
@@ -2491,7 +2677,7 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
             if (rc != X3D_OK) return rc;
         }
     }
-    for (int v = 0; v < 8; ++v) {
+    for (int v = 0; v < 10; ++v) {
         const int rc = launch(v);
         if (rc != X3D_OK) return rc;
     }
