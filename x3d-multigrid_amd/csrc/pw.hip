@@ -26,6 +26,10 @@ bool x3d_pw6_ok(int K, int M, int P);
 int x3d_pw6_tiles(int P);
 int x3d_pw6_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M,
                    int P, int in_act, hipStream_t s);
+bool x3d_pwfs_ok(int K, int M, int P);
+int x3d_pwfs_tiles(int N, int P);
+int x3d_pwfs_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M, int P,
+                    int in_act, hipStream_t s);
 bool x3d_pw7_ok(int K, int M, int P);
 int x3d_pw7_launch(const float* g, const float* a, const float* cb, const float* wpt, float* out, float* partial, int mode,
                    const float* ex, const float* emask, const float* ecoef, int e_act, const float* addend,
@@ -2437,6 +2441,7 @@ extern "C" int x3d_pw_tiles(int N, int K, int M, int P, int dense) {
 // tiles of the forward's `partial`: the large-channel forward kernel (packed weights, dense) works on 32-voxel items
 extern "C" int x3d_pw_fwd_tiles(int N, int Cin, int Cout, int P, int dense, int packed) {
     if (packed && dense && x3d_pw6_ok(Cin, Cout, P)) return x3d_pw6_tiles(P);
+    if (packed && dense && x3d_pwfs_ok(Cin, Cout, P)) return x3d_pwfs_tiles(N, P);
     return x3d_pw_tiles(N, Cin, Cout, P, dense);
 }
 
@@ -2490,6 +2495,8 @@ extern "C" int x3d_pw_fwd(const float* x, const float* w, const float* wpacked, 
     hipStream_t s = (hipStream_t)stream;
     if (wpacked != nullptr && strideHW == 1 && x3d_pw6_ok(Cin, Cout, A.P))
         return x3d_pw6_launch(x, pre, wpacked, y, partial, N, Cin, Cout, A.P, pre_act, s);
+    if (wpacked != nullptr && strideHW == 1 && x3d_pwfs_ok(Cin, Cout, A.P))
+        return x3d_pwfs_launch(x, pre, wpacked, y, partial, N, Cin, Cout, A.P, pre_act, s);
     if (pre) return launch_pw<IN_AFFACT, EPI_STATS>(A, s);
     return launch_pw<IN_RAW, EPI_STATS>(A, s);
 }

@@ -412,6 +412,219 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
             }
 }
 
+// ---------------------------------------------------------------------------------------
+// Forward of the stage 1-2 pointwise convs in the same architecture (round 2): persistent 8-wave workgroups over 64-voxel
+// chunks, the activation rows of chunk c+1 requested before the MFMAs of chunk c, X staged as THREE bf16 planes
+// (hi + mid + lo: fp32-level accuracy, six MFMA products -- pw6.hip has the argument) read transposed as the B operand, the
+// pre-split forward weight pack copied into LDS once per workgroup, BN statistics per (row, chunk) in the epilogue.
+// Replaces the fp32-MFMA streaming kernel pw3 (3.3-3.5 TB/s at 2 waves per SIMD) for dense inputs with K, M <= 128.
+// ---------------------------------------------------------------------------------------
+struct FsArgs {
+    const float* x; const float* cin; int in_act;      // [N][K][P]; [N][K][2] or NULL
+    const float* wp;                                    // forward pack: fp32 image, then bf16 hi / mid / lo planes
+    float* y; float* partial;                           // [N][M][P]; [N][M][tiles][2] or NULL
+    int N, K, M, P, tiles;
+};
+
+template <int KP, int MP, int NWV>
+__global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs A) {
+    constexpr int NT = 64 * NWV, RP = NT / 16;
+    constexpr int NX = (KP + RP - 1) / RP;
+    constexpr int KS = KP / 32;
+    constexpr int MPW = NWV / 2;                           // waves per voxel half
+    constexpr int U = (MP / 16 + MPW - 1) / MPW;           // units per wave: m tiles (wave >> 1) + MPW j
+    __shared__ __attribute__((aligned(16))) __bf16 Xh[KP * F_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Xm[KP * F_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Xl[KP * F_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Wl[(MP / 16) * KS * 3 * 64 * 8];
+    __shared__ float red[NWV * U * 16 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int half = wave & 1, mpar = wave >> 1;
+    const int P = A.P, K = A.K, M = A.M;
+    const int cps = (P + F_PT - 1) / F_PT;
+    const int total = A.N * cps;
+    const int G = gridDim.x;
+    const int c4 = (tid & 15) * 4, row0 = tid >> 4;
+    const int colE = (c4 & 32) + ((c4 & 31) >> 1), colO = colE + 16;
+
+    // forward weight pack -> LDS ([m tile][k step][plane][lane][8]), once
+    {
+        const int mtiles = (M + 15) / 16, kg16 = (K + 15) / 16, kg32 = (K + 31) / 32;
+        const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
+        const size_t plane = (size_t)mtiles * kg32 * 512;
+        for (int i = tid; i < (MP / 16) * KS * 3 * 64; i += NT) {
+            const int ln = i & 63, rest = i >> 6;
+            const int pl = rest % 3, rest2 = rest / 3;
+            const int s = rest2 % KS, mt = rest2 / KS;
+            const int mtc = min(mt, mtiles - 1), sc_ = min(s, kg32 - 1);      // clamped: never stored / zero X rows
+            *reinterpret_cast<bf16x8*>(&Wl[(size_t)i * 8]) =
+                *reinterpret_cast<const bf16x8*>(wq + pl * plane + (((size_t)mtc * kg32 + sc_) * 64 + ln) * 8);
+        }
+    }
+
+    // chunk c of this workgroup's CONTIGUOUS range (see the main loop); two chunks are in flight in two register sets
+    auto fetch = [&](int c, float4 (&rx)[NX], float2 (&cf)[NX]) {
+        const int n = c / cps, pt = (c - n * cps) * F_PT;
+        const int pc = min(pt + c4, P - 4);
+        const float* xs = A.x + (size_t)n * K * (size_t)P;
+        const float* cs = A.cin != nullptr ? A.cin + (size_t)n * K * 2 : nullptr;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const unsigned k = (unsigned)min(row0 + RP * i, K - 1);
+            rx[i] = ldg_off<float4>(xs, (k * (unsigned)P + (unsigned)pc) * 4u);
+            cf[i] = make_float2(1.f, 0.f);
+            if (cs != nullptr) cf[i] = ldg_off<float2>(cs, k * 8u);
+        }
+    };
+    auto store = [&](int c, const float4 (&rx)[NX], const float2 (&cf)[NX]) {
+        const int pt = (c % cps) * F_PT;
+        const bool pvv = pt + c4 < P;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int row = row0 + RP * i;
+            if (KP % RP == 0 || row < KP) {
+                const bool ok = pvv && row < K;
+                float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+                if (A.cin != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(cf[i].x, v[e], cf[i].y), A.in_act);
+                }
+                bf16x2 he, ho, me, mo, le, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = ok ? v[e] : 0.f;
+                    const __bf16 h = (__bf16)x0;
+                    const float r1 = x0 - (float)h;
+                    const __bf16 m = (__bf16)r1;
+                    const __bf16 l = (__bf16)(r1 - (float)m);
+                    if (e & 1) { ho[e >> 1] = h; mo[e >> 1] = m; lo[e >> 1] = l; } else { he[e >> 1] = h; me[e >> 1] = m; le[e >> 1] = l; }
+                }
+                *reinterpret_cast<bf16x2*>(&Xh[row * F_LD + colE]) = he;
+                *reinterpret_cast<bf16x2*>(&Xh[row * F_LD + colO]) = ho;
+                *reinterpret_cast<bf16x2*>(&Xm[row * F_LD + colE]) = me;
+                *reinterpret_cast<bf16x2*>(&Xm[row * F_LD + colO]) = mo;
+                *reinterpret_cast<bf16x2*>(&Xl[row * F_LD + colE]) = le;
+                *reinterpret_cast<bf16x2*>(&Xl[row * F_LD + colO]) = lo;
+            }
+        }
+    };
+
+    f32x4 acc[U][2];
+    const int tr_off = (8 * q + (r >> 2)) * F_LD + 4 * (r & 3) + 32 * half;
+    auto tr_frag = [&](const __bf16* plane, int s, int h2) -> bf16x8 {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const __bf16* p0 = plane + 32 * s * F_LD + tr_off + 16 * h2;
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * F_LD));
+        return cat8(v0, v1);
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int j = 0; j < U; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) { bh[h2] = tr_frag(Xh, s, h2); bm[h2] = tr_frag(Xm, s, h2); bl[h2] = tr_frag(Xl, s, h2); }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int mt = min(mpar + MPW * j, MP / 16 - 1);
+                const __bf16* wb = &Wl[((mt * KS + s) * 3 * 64 + lane) * 8];
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wb);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(wb + 64 * 8);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wb + 2 * 64 * 8);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[h2], acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[h2], acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[h2], acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[h2], acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[h2], acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[h2], acc[j][h2], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // BN statistics of this workgroup's chunks of ONE sample, accumulated in registers (every lane of a 16-lane row group
+    // holds its rows' sums) and written as one partial per (sample, row, workgroup) when the range leaves the sample
+    float sa[U][4][2];
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sa[j][e][0] = 0.f; sa[j][e][1] = 0.f; }
+    auto epilogue = [&](int c, bool flush) {
+        const int n = c / cps, tile = c - n * cps;
+        const int pl = tile * F_PT + 32 * half + 2 * r;
+        const bool pv = pl < P;
+        float* ys = A.y + (size_t)n * M * (size_t)P;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int lt = mpar + MPW * j;
+            if (lt * 16 >= MP) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = lt * 16 + 4 * q + e;
+                const bool mv = ml < M;
+                const float v0 = pv ? acc[j][0][e] : 0.f, v1 = pv ? acc[j][1][e] : 0.f;
+                if (mv && pv)
+                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(ys) + ((unsigned)ml * (unsigned)P + (unsigned)pl) * 4u) =
+                        make_float2(v0, v1);
+                sa[j][e][0] += row16_sum(v0 + v1);
+                sa[j][e][1] += row16_sum(fmaf(v0, v0, v1 * v1));
+                if (flush) {
+                    if (r == 0) {
+                        red[((wave * U + j) * 16 + 4 * q + e) * 2] = mv ? sa[j][e][0] : 0.f;
+                        red[((wave * U + j) * 16 + 4 * q + e) * 2 + 1] = mv ? sa[j][e][1] : 0.f;
+                    }
+                    sa[j][e][0] = 0.f; sa[j][e][1] = 0.f;
+                }
+            }
+        }
+    };
+    // workgroup w owns chunks [w total / G, (w + 1) total / G); w_of(c) is the owner of chunk c
+    const int wg = blockIdx.x;
+    auto w_of = [&](long long c) { return (int)(((c + 1) * G - 1) / total); };
+    auto write_stats = [&](int n) {
+        const int w_first = w_of((long long)n * cps), w_last = w_of((long long)(n + 1) * cps - 1);
+        const int slot = wg - w_first;
+        for (int idx = tid; idx < M * 2; idx += NT) {
+            const int ml = idx >> 1, which = idx & 1;
+            const int lt = ml >> 4, wv = (lt % MPW) * 2, j = lt / MPW;
+            const float sv = red[((wv * U + j) * 16 + (ml & 15)) * 2 + which] +
+                             red[(((wv + 1) * U + j) * 16 + (ml & 15)) * 2 + which];
+            float* pp = A.partial + (((size_t)n * M + ml) * A.tiles) * 2 + which;
+            pp[(size_t)slot * 2] = sv;
+            if (wg == w_last)                              // the sample's last workgroup clears the slots nobody owns
+                for (int t = slot + 1; t < A.tiles; ++t) pp[(size_t)t * 2] = 0.f;
+        }
+    };
+
+    const int c_begin = (int)(((long long)wg * total) / G), c_end = (int)(((long long)(wg + 1) * total) / G);
+    if (c_begin < c_end) {
+        float4 rxa[NX], rxb[NX];
+        float2 cfa[NX], cfb[NX];
+        fetch(c_begin, rxa, cfa);
+        if (c_begin + 1 < c_end) fetch(c_begin + 1, rxb, cfb);
+        auto iter = [&](int c, float4 (&rcur)[NX], float2 (&ccur)[NX]) {
+            store(c, rcur, ccur);
+            __syncthreads();                 // chunk staged
+            if (c + 2 < c_end) fetch(c + 2, rcur, ccur);     // two chunks ahead, into the set just consumed
+            compute();
+            const bool flush = (c + 1 == c_end) || ((c + 1) / cps != c / cps);
+            epilogue(c, flush && A.partial != nullptr);
+            __syncthreads();                 // images free; red[] complete
+            if (flush && A.partial != nullptr) write_stats(c / cps);
+        };
+        for (int c = c_begin; c < c_end; c += 2) {
+            iter(c, rxa, cfa);
+            if (c + 1 < c_end) iter(c + 1, rxb, cfb);
+        }
+    }
+}
+
 static int fb_pad32(int c) { return (c + 31) / 32 * 32; }
 
 // residual mode: instantiated only where its three raw tiles fit the LDS (x3d_pw_bwd_fused_ok refuses the others)
@@ -495,6 +708,39 @@ extern "C" int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb,
     else FB_LAUNCH(128, 64, 16, 4);
 #undef FB_LAUNCH
 #undef FB_LAUNCH2
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+// ---- forward, stages 1-2 (pw_fwd_stream_kernel): dense, K, M <= 128, P % 4 == 0
+bool x3d_pwfs_ok(int K, int M, int P) {
+    static const bool off = getenv("X3D_NO_PWFS") != nullptr;
+    // measured at the base shape (gpurun_out/r2/launches{19,21}.json): the expanding convs (K = 24 / 48 -> M = 54 / 108: the
+    // output stream dominates) gain 20-25 % over the fp32-MFMA streaming kernel pw3; the contracting ones (K = 54 / 108 ->
+    // M = 24 / 48: Swish + 3-way split of a wide input, a third of the waves idle in the MFMA phase, 100 KB of LDS at
+    // K = 108) lose 15-30 % and stay on pw3
+    return !off && K <= 64 && M >= K && M <= 128 && (P % 4 == 0) && P >= 4;
+}
+
+// statistics slots per sample: one per workgroup whose contiguous chunk range touches the sample
+int x3d_pwfs_tiles(int N, int P) {
+    const int G = x3d_pw_bwd_fused_groups(N, P);
+    return (G + N - 1) / N + 1;
+}
+
+extern "C" int x3d_pw_bwd_fused_groups(int N, int P);
+int x3d_pwfs_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M, int P,
+                    int in_act, hipStream_t s) {
+    FsArgs A = {};
+    A.x = x; A.cin = cin; A.in_act = in_act; A.wp = wp; A.y = y; A.partial = partial;
+    A.N = N; A.K = K; A.M = M; A.P = P; A.tiles = x3d_pwfs_tiles(N, P);
+    const dim3 grid(x3d_pw_bwd_fused_groups(N, P)), blk(512);
+    const int kp = fb_pad32(K) == 96 ? 128 : fb_pad32(K), mp = fb_pad32(M) == 96 ? 128 : fb_pad32(M);
+#define FS_GO(KP_, MP_) hipLaunchKernelGGL((pw_fwd_stream_kernel<KP_, MP_, 8>), grid, blk, 0, s, A)
+    if (kp == 32) { if (mp == 32) FS_GO(32, 32); else if (mp == 64) FS_GO(32, 64); else FS_GO(32, 128); }
+    else if (kp == 64) { if (mp == 32) FS_GO(64, 32); else if (mp == 64) FS_GO(64, 64); else FS_GO(64, 128); }
+    else { if (mp == 32) FS_GO(128, 32); else if (mp == 64) FS_GO(128, 64); else FS_GO(128, 128); }
+#undef FS_GO
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
