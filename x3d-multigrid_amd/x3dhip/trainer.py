@@ -117,6 +117,7 @@ class Trainer:
         self.num_steps_per_update = int(num_steps_per_update)
         self._micro = 0
         self.accum = torch.zeros_like(self.fp.grad) if self.num_steps_per_update > 1 else None
+        self._acc_reducer = None
         self.stepped = False
         self.param_groups = [dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay,
                                   nesterov=False, params=list(range(len(self.fp.params))))]
@@ -234,12 +235,11 @@ class Trainer:
         self.stepped = self._micro == K
         if self.stepped:
             self._micro = 0
-            if self.world > 1:
+            if self.reducer.active:
                 # one exchange per optimizer step, on the accumulated gradient (no overlap with a backward pass here)
-                acc_reducer = GradReducer(self.accum, self.reducer.buffers_like(), self.world, self.pg) \
-                    if not hasattr(self, "_acc_reducer") else self._acc_reducer
-                self._acc_reducer = acc_reducer
-                acc_reducer.reduce()
+                if self._acc_reducer is None:
+                    self._acc_reducer = GradReducer(self.accum, self.reducer.buffers_like(), self.world, self.pg)
+                self._acc_reducer.reduce()
             if pre_step is not None:
                 pre_step()
             self._sgd(self.accum)
