@@ -284,10 +284,12 @@ def main():
         "metric": "clips/sec X3D-M fwd+bwd+SGD at multigrid base shape (whole job)",
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        # storage, forward GEMMs, stencils, BN and the optimizer are fp32; the backward pointwise GEMMs multiply fp32 operands
-        # split into hi + lo bf16 (3 MFMA products, fp32 accumulate, ~2^-16 per product) -- value_exact_fp32 is the same
-        # job with the exact fp32-MFMA backward kernels
-        "dtype": "f32 (backward pointwise GEMMs: split-bf16x3 operands, fp32 accumulate)", "data": "synthetic",
+        # storage, stencils, BN and the optimizer are fp32.  Pointwise GEMMs run on the bf16 MFMA with fp32 operands split into
+        # bf16 terms, fp32 accumulate: forward 3 terms / 6 products (all 24 significant bits: fp32-level accuracy; the
+        # contracting stage 1-2 convs still use the fp32 MFMA), backward 2 terms / 3 products (~2^-16 per product) --
+        # value_exact_fp32 is the same job with the exact fp32-MFMA backward kernels
+        "dtype": "f32 (pointwise GEMMs: fp32 operands split into bf16 terms on the MFMA, fp32 accumulate; fwd 3-term = "
+                 "fp32-level, bwd 2-term ~2^-16)", "data": "synthetic",
         "config": {"workload": "X3D-M train step B=%d/GPU T=%d H=W=%d, 400 classes, dropout 0.5, SGD momentum" % (B, T, H),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "launch": "eager" if args.no_graph else "hipGraph(fwd+bwd) + SGD",

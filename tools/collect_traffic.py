@@ -41,7 +41,7 @@ def fam(name):
     template argument tells them apart (IN = 2 is the BN-backward prologue of the data gradient)."""
     if "pw_bwd_fused_kernel" in name:
         return "pw_bwd_fused"
-    if "pw6_kernel" in name:
+    if "pw6_kernel" in name or "pw_fwd_stream_kernel" in name:
         return "pw_fwd"
     if "pw7_kernel" in name or "pw5_kernel" in name:
         return "pw_bwd_data"

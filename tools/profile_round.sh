@@ -13,4 +13,4 @@ python tools/profile_summary.py $(ls gpurun_out/r2/prof/kt/*/*.db | head -1) gpu
 python tools/collect_traffic.py gpurun_out/r2/prof/pmc_fetch gpurun_out/r2/prof/pmc_write gpurun_out/r2/prof/traffic.json > gpurun_out/r2/prof/traffic.txt 2>&1
 python tools/collect_pmc.py gpurun_out/r2/prof/pmc_lds gpurun_out/r2/prof/pmc_mfma gpurun_out/r2/prof/pmc_sq.json > gpurun_out/r2/prof/pmc_sq.txt 2>&1
 rm -rf gpurun_out/r2/prof/pmc_fetch gpurun_out/r2/prof/pmc_write gpurun_out/r2/prof/pmc_lds gpurun_out/r2/prof/pmc_mfma gpurun_out/r2/prof/kt
-tail -5 gpurun_out/r2/prof/*.txt gpurun_out/r2/prof/pmc_l.log gpurun_out/r2/prof/pmc_m.log
+echo done
