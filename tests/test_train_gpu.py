@@ -381,3 +381,19 @@ def test_rccl_world_size_one_split_graph(monkeypatch):
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
     assert torch.equal(res[0][1], res[1][1])                   # sum over one rank == identity: bit-identical
     assert torch.equal(res[0][2], res[1][2])
+
+
+def test_run_stops_at_the_end_of_the_schedule_and_saves(tmp_path):
+    """The schedule generator has no end of its own (its long-cycle lookup runs off the table one step past
+    schedule[-1]); run() must stop at lr_schedule[-1] like the reference's max_epochs bound (train...:192), write the
+    final checkpoint and return cleanly."""
+    _dev()
+    import train_x3d_kinetics_multigrid as tr
+    save = str(tmp_path / "end_")
+    steps, cps = tr.run(init_lr=0.01, warmup_steps=2, max_epochs=1, batch_size=2, steps=0, max_steps_run=None,
+                        iterations_per_epoch=9, save_model=save, save_every=1000, use_graph=False, log_every=100,
+                        clip_size=32)
+    assert steps == 9 and cps > 0
+    assert os.path.exists(save + "000009.pt")
+    ck = torch.load(save + "000009.pt", map_location="cpu")
+    assert ck["scheduler_state_dict"]["last_epoch"] == 9
