@@ -29,25 +29,34 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
-def algorithmic_elems_M(T, H):
-    """E(T,H,W) of SURVEY.md 8(d) for X3D-S/M (elements per clip): sum over every Conv3d of
-    in+out elements + 3 x block outputs."""
+_ARCH = {  # (cm, co, blocks) per stage: x3d.py:352-363 ("L": XL depth at M width)
+    "S": [(54, 24, 3), (108, 48, 5), (216, 96, 11), (432, 192, 7)],
+    "M": [(54, 24, 3), (108, 48, 5), (216, 96, 11), (432, 192, 7)],
+    "L": [(54, 24, 5), (108, 48, 10), (216, 96, 25), (432, 192, 15)],
+    "XL": [(72, 32, 5), (162, 72, 10), (306, 136, 25), (630, 280, 15)],
+}
+
+
+def algorithmic_elems_M(T, H, version="M"):
+    """E(T,H,W) of SURVEY.md 8(d) (elements per clip): sum over every Conv3d of in+out elements + 3 x block outputs."""
     def o(h):
         return (h - 1) // 2 + 1
     h = [H]
     for _ in range(5):
         h.append(o(h[-1]))
     S = [T * v * v for v in h]          # S[0]=input res, S[1]=stem res, S[2..5]=stage outputs
-    E = 3 * S[0] + 24 * S[1] + 2 * 24 * S[1]       # conv1_s in+out, conv1_t in+out
-    cin = 24
-    for k, (cm, co, n) in enumerate([(54, 24, 3), (108, 48, 5), (216, 96, 11), (432, 192, 7)]):
+    arch = _ARCH[version]
+    c0 = arch[0][1]
+    E = 3 * S[0] + c0 * S[1] + 2 * c0 * S[1]       # conv1_s in+out, conv1_t in+out
+    cin = c0
+    for k, (cm, co, n) in enumerate(arch):
         sp, sk = S[k + 1], S[k + 2]
         # first block: conv1 (cin->cm @sp), conv2 (cm @sp -> @sk), conv3 (cm->co @sk), downsample (cin @sk sampled -> co @sk)
         E += (cin + cm) * sp + cm * (sp + sk) + (cm + co) * sk + cin * sp + co * sk
         E += (n - 1) * ((co + cm) * sk + 2 * cm * sk + (cm + co) * sk)
         E += 3 * n * co * sk
         cin = co
-    E += (192 + 432) * S[5] + 432 + 2048
+    E += (arch[3][1] + arch[3][0]) * S[5] + arch[3][0] + 2048
     return E
 
 
@@ -199,6 +208,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--model", default="M", choices=["S", "M", "L", "XL"],
+                    help="model version (headline: M; 'L' at --size 312 is BASELINE configs[4]'s architecture, fp32 storage here)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -235,7 +246,7 @@ def main():
 
     B, T, H = args.batch, args.frames, args.size
     torch.manual_seed(0)
-    net = x3d.generate_model("M", n_classes=400, dropout=0.5, base_bn_splits=max(1, B // 8)).to(dev).train(True)
+    net = x3d.generate_model(args.model, n_classes=400, dropout=0.5, base_bn_splits=max(1, B // 8)).to(dev).train(True)
     tr = Trainer(net, lr=0.05, process_group=pg, world_size=world, use_graph=not args.no_graph)
     x = synthetic.synthetic_clips(B, T, H, H, seed=1234 + rank).to(dev)
     y = synthetic.synthetic_labels(B, seed=1234 + rank).to(dev)
@@ -278,10 +289,11 @@ def main():
         del os.environ["X3D_DGRAD_F32"], os.environ["X3D_WGRAD_F32"]
         tr.invalidate_graphs()
 
-    E = algorithmic_elems_M(T, H)
-    step_bytes = B * 3 * 4 * E + 20 * 3794322
+    E = algorithmic_elems_M(T, H, args.model)
+    nparams = sum(p.numel() for p in net.parameters())
+    step_bytes = B * 3 * 4 * E + 20 * nparams
     out = {
-        "metric": "clips/sec X3D-M fwd+bwd+SGD at multigrid base shape (whole job)",
+        "metric": "clips/sec X3D-%s fwd+bwd+SGD at multigrid base shape (whole job)" % args.model,
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         # storage, stencils, BN and the optimizer are fp32.  Pointwise GEMMs run on the bf16 MFMA with fp32 operands split into
@@ -290,7 +302,7 @@ def main():
         # value_exact_fp32 is the same job with the exact fp32-MFMA backward kernels
         "dtype": "f32 (pointwise GEMMs: fp32 operands split into bf16 terms on the MFMA, fp32 accumulate; fwd 3-term = "
                  "fp32-level, bwd 2-term ~2^-16)", "data": "synthetic",
-        "config": {"workload": "X3D-M train step B=%d/GPU T=%d H=W=%d, 400 classes, dropout 0.5, SGD momentum" % (B, T, H),
+        "config": {"workload": "X3D-%s train step B=%d/GPU T=%d H=W=%d, 400 classes, dropout 0.5, SGD momentum" % (args.model, B, T, H),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "launch": "eager" if args.no_graph else "hipGraph(fwd+bwd) + SGD",
                    # storage, forward GEMMs, stencils, BN: fp32.  Backward pointwise GEMMs: fp32 operands split into
@@ -370,7 +382,7 @@ def main():
                            "share_of_step_device_time": round(tms / tot, 3)}
         out["kernel_breakdown_ms"] = {k: [round(v[0], 3), v[2], round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0]
                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "M":
         out["cpu_baseline"] = cpu_baseline(T, H)
     if world > 1:
         import torch.distributed as dist
