@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define X3D_ABI_VERSION 4
+#define X3D_ABI_VERSION 5
 
 #define X3D_OK 0
 #define X3D_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
@@ -40,6 +40,17 @@ extern "C" {
 #define X3D_ACT_NONE 0
 #define X3D_ACT_RELU 1   /* nn.ReLU           x3d.py:119,148,169,210 */
 #define X3D_ACT_SWISH 2  /* SwishEfficient    x3d.py:71-84 */
+
+/* Mixed-storage mode (ABI 5; BASELINE config 5 "bf16 storage / fp32 accumulate"): the `mx` argument of the pointwise and
+ * channelwise entry points says which ACTIVATION tensors of that call are stored as bf16 (2 bytes per element, same
+ * [N][C][T][H][W] order) instead of fp32 -- in the model these are the wide (planes = 2.25 x width) tensors inside a
+ * bottleneck (x3d.py:112-116: conv1 output, conv2 output and their gradients).  Everything else (weights, packs, BN
+ * coefficients, statistics partials, weight-gradient partials, narrow activations) is fp32; every product is accumulated
+ * in fp32; a bf16 store rounds to nearest even.  mx = 0 is the fp32 path, bitwise what ABI 4 computed.  A combination an
+ * entry point has no kernel for returns X3D_EINVAL (never a silent fallback). */
+#define X3D_MX_X 1    /* the forward input x of the convolution (also where it is re-read by the backward entries) */
+#define X3D_MX_Y 2    /* the tensor the call writes: forward y, backward out / dx */
+#define X3D_MX_GA 4   /* the upstream gradient g AND the raw forward output a it is combined with */
 
 int x3d_abi_version(void);
 const char* x3d_last_error(void);
@@ -56,8 +67,8 @@ const char* x3d_last_error(void);
 int x3d_pw_tiles(int N, int K, int M, int P, int dense);
 /* tiles of x3d_pw_fwd's `partial` (packed = 1 when wpacked is passed: the large-channel layers then run on 32-voxel items) */
 int x3d_pw_fwd_tiles(int N, int Cin, int Cout, int P, int dense, int packed);
-/* tiles of x3d_pw_bwd_data's / x3d_pw_bwd_data_res's `partial` (packed = 1 when wpacked_t is passed) */
-int x3d_pw_bwd_tiles(int N, int Cin, int Cout, int P, int packed);
+/* tiles of x3d_pw_bwd_data's / x3d_pw_bwd_data_res's `partial` (packed = 1 when wpacked_t is passed; mx as in the call) */
+int x3d_pw_bwd_tiles(int N, int Cin, int Cout, int P, int packed, int mx);
 
 /* Forward.  in[ci,p] = act(pre[n,ci,0] * x + pre[n,ci,1]) when pre != NULL (fuses the
  * producer's BN-apply + ReLU, or BN-apply * SE-scale + Swish: x3d.py:147-148,151-160), else x.
@@ -82,10 +93,10 @@ int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int transposed, vo
 size_t x3d_pw_pack_job_bytes(void);
 int x3d_pw_pack_batch(const void* jobs, const int* wg_job, int n_workgroups, void* stream);
 
-int x3d_pw_fwd(const float* x, const float* w, const float* wpacked, float* y,
+int x3d_pw_fwd(const void* x, const float* w, const float* wpacked, void* y,
                int N, int Cin, int Cout, int T, int H, int W, int strideHW,
                const float* pre, int pre_act,
-               float* partial, void* stream);
+               float* partial, int mx /* X3D_MX_X | X3D_MX_Y; stride 1 with wpacked only */, void* stream);
 
 /* Backward-data (autograd of the conv above, fused with the BN backward that precedes it in
  * the backward pass and with the activation backward that follows it):
@@ -98,12 +109,13 @@ int x3d_pw_fwd(const float* x, const float* w, const float* wpacked, float* y,
  *               output; SwishEfficient.backward x3d.py:80-84 / ReLU backward)
  * partial (NULL unless pre != NULL) gets per-(n,ci,tile) {sum out, sum out*x}.
  * Geometry: g,a are [N,Cout,T,H,W]; out,x are [N,Cin,T,H,W]. */
-int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float* w,
+int x3d_pw_bwd_data(const void* g, const void* a, const float* cb, const float* w,
                     const float* wpacked_t,
-                    float* out, int N, int Cin, int Cout, int T, int H, int W,
-                    const float* x, const float* pre, int pre_act,
+                    void* out, int N, int Cin, int Cout, int T, int H, int W,
+                    const void* x, const float* pre, int pre_act,
                     const float* addend, int addend_stride,
-                    float* partial, void* stream);
+                    float* partial, int mx /* X3D_MX_GA | X3D_MX_X (x) | X3D_MX_Y (out); with wpacked_t only */,
+                    void* stream);
 
 /* The same data gradient with the residual-add + ReLU backward of the block that PRODUCED this conv's input folded into
  * the epilogue (x3d.py:165-169 backward; what x3d_bn_add_relu_bwd does in a launch of its own for blocks without a
@@ -111,9 +123,10 @@ int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float
  *   out[ci,p] = (dIn[ci,p] + addend) where res_out[ci,p] > 0, else 0      (= g3 of that block)
  *   partial   = per-(n,ci,tile) {sum out, sum out*res_raw}                 (its bn3 backward statistics)
  * res_out = that block's output [N,Cin,T,H,W], res_raw = its raw conv3 output. */
-int x3d_pw_bwd_data_res(const float* g, const float* a, const float* cb, const float* w, const float* wpacked_t,
+int x3d_pw_bwd_data_res(const void* g, const void* a, const float* cb, const float* w, const float* wpacked_t,
                         float* out, int N, int Cin, int Cout, int T, int H, int W, const float* res_out,
-                        const float* res_raw, const float* addend, int addend_stride, float* partial, void* stream);
+                        const float* res_raw, const float* addend, int addend_stride, float* partial,
+                        int mx /* X3D_MX_GA only */, void* stream);
 
 /* Fused backward (stages 1-2): the data gradient AND the weight-gradient partials of one pointwise convolution from ONE
  * pass over g, a and x -- ConvolutionBackward's grad_input + grad_weight of conv1x1x1 (x3d.py:98-103 as Bottleneck.conv1 /
@@ -129,29 +142,30 @@ int x3d_pw_bwd_data_res(const float* g, const float* a, const float* cb, const f
  * wpartial is float[x3d_pw_bwd_fused_groups(N,P)][Cout][Cin] (x3d_reduce_partials sums it); partial is
  * float[N][Cin][x3d_pw_bwd_fused_tiles(P)][2].  x3d_pw_bwd_fused_ok tells whether (Cin, Cout, P, mode, addend) is in the kernel's set
  * (dense, P % 4 == 0, both channel counts <= 128); other shapes use the separate entry points. */
-int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P, int mode, int has_addend);
+/* mx: 0; X3D_MX_GA (g, a bf16: any mode); X3D_MX_X | X3D_MX_Y (x and dx bf16: mode 1 without addend) */
+int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P, int mode, int has_addend, int mx);
 int x3d_pw_bwd_fused_groups(int N, int P);
 int x3d_pw_bwd_fused_tiles(int P);
-int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb, const float* wpacked_t, const float* x,
+int x3d_pw_bwd_fused(const void* g, const void* a, const float* cb, const float* wpacked_t, const void* x,
                      const float* xpre, int xact, int mode, const float* ex, const float* addend, int addend_stride,
-                     float* dx, float* wpartial, float* partial, int N, int Cin, int Cout, int T, int H, int W,
-                     void* stream);
+                     void* dx, float* wpartial, float* partial, int N, int Cin, int Cout, int T, int H, int W,
+                     int mx, void* stream);
 
 /* Backward-weight: dW[co,ci] = sum_{n,p} dY[co,p] * in[ci,p] with dY and in formed as above
  * (strideHW 2: in is sampled at even (h,w) of x[N,Cin,T,H,W]; g,a are at output resolution).
  * wpartial is float[x3d_pw_wgrad_groups(...)][Cout][Cin]; x3d_reduce_partials sums it. */
 int x3d_pw_wgrad_groups(int N, int P, int Cout, int Cin, int strideHW);
-int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb,
-                      const float* x, const float* pre, int pre_act,
+int x3d_pw_bwd_weight(const void* g, const void* a, const float* cb,
+                      const void* x, const float* pre, int pre_act,
                       float* wpartial, int N, int Cin, int Cout, int T, int H, int W,
-                      int strideHW, void* stream);
+                      int strideHW, int mx /* X3D_MX_GA | X3D_MX_X; the MFMA tile variants only */, void* stream);
 
 /* Several weight gradients in as few launches as there are tile variants among them (jobs: the arguments of
  * x3d_pw_bwd_weight, one struct per conv).  Nothing in the backward pass consumes a weight gradient, so the host may
  * postpone them all to the end of the pass; results are bitwise those of the single calls. */
 typedef struct X3DWgradJob {
-    const float* g; const float* a; const float* cb; const float* x; const float* pre; float* wpartial;
-    int pre_act, N, Cin, Cout, T, H, W, strideHW;
+    const void* g; const void* a; const float* cb; const void* x; const float* pre; float* wpartial;
+    int pre_act, N, Cin, Cout, T, H, W, strideHW, mx;
 } X3DWgradJob;
 size_t x3d_wgrad_job_bytes(void);
 int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void* stream);
@@ -173,19 +187,20 @@ int x3d_dw_tiles(int N, int C, int H_out, int W_out);  /* spatial tiles per (n,c
 /* y = dw333(relu(pre*x+pre) zero-padded).  partial: float[N][C][tiles][2] {sum y, sum y^2}.
  * pre_act of the channelwise entries: X3D_ACT_RELU or X3D_ACT_NONE only (x3d.py:147-150: ReLU precedes conv2);
  * X3D_ACT_SWISH returns X3D_EINVAL. */
-int x3d_dw333_fwd(const float* x, const float* w, float* y,
+int x3d_dw333_fwd(const void* x, const float* w, void* y,
                   int N, int C, int T, int H, int W, int strideHW,
-                  const float* pre, int pre_act, float* partial, void* stream);
+                  const float* pre, int pre_act, float* partial, int mx /* 0 or X3D_MX_X | X3D_MX_Y */, void* stream);
 
 /* Training form with the producer BN's finalize folded in (one launch less per block): the scale / shift applied while
  * loading x are derived inside the kernel from the producer conv's statistics partials
  * spartial float[N][C][stiles][2] (x3d.py:47-58; S splits, `count` voxels per (n, c), eps, running statistics with
  * momentum / unbiased variance).  coef_out float[N][C][2] and save float[2][S][C] (mean, invstd) are written for the
  * backward pass. */
-int x3d_dw333_fwd_stats(const float* x, const float* w, float* y, int N, int C, int T, int H, int W, int strideHW,
+int x3d_dw333_fwd_stats(const void* x, const float* w, void* y, int N, int C, int T, int H, int W, int strideHW,
                         const float* spartial, int stiles, int S, int count, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, float* save,
-                        float* coef_out, int pre_act, float* partial, void* stream);
+                        float* coef_out, int pre_act, float* partial, int mx /* 0 or X3D_MX_X | X3D_MX_Y */,
+                        void* stream);
 
 /* Fused backward (data + weight) of the conv above:
  *   dY = cb0*g + cb1*a + cb2 (g,a at output resolution [N,C,T,Ho,Wo])
@@ -194,18 +209,20 @@ int x3d_dw333_fwd_stats(const float* x, const float* w, float* y, int N, int C, 
  *   dW[c,kt,kh,kw] partials: float[N][x3d_dw_bwd_tiles(N,C,H,W,s)][C][27] (group-sum over the first two dims)
  *   partial: float[N][C][x3d_dw_bwd_tiles(N,C,H,W,s)][2] {sum out, sum out*x}  */
 int x3d_dw_bwd_tiles(int N, int C, int H, int W, int strideHW);
-int x3d_dw333_bwd(const float* g, const float* a, const float* cb, const float* w,
-                  const float* x, const float* pre, int pre_act,
-                  float* out, float* wpartial, float* partial,
-                  int N, int C, int T, int H, int W, int strideHW, void* stream);
+int x3d_dw333_bwd(const void* g, const void* a, const float* cb, const float* w,
+                  const void* x, const float* pre, int pre_act,
+                  void* out, float* wpartial, float* partial,
+                  int N, int C, int T, int H, int W, int strideHW,
+                  int mx /* 0 or X3D_MX_GA | X3D_MX_X | X3D_MX_Y: g, a, x and out are the same four wide tensors */,
+                  void* stream);
 
 /* The same with the producer BN's backward finalize folded in (single split, num_splits == 1): the coefficients are
  * derived inside the kernel from spartial float[N][C][stiles][2] = {sum g, sum g*a} (the statistics the kernel that
  * wrote g left), gamma and save = {mean[C], invstd[C]}; dgamma / dbeta float[C] are written (not accumulated). */
-int x3d_dw333_bwd_stats(const float* g, const float* a, const float* spartial, int stiles, int count,
+int x3d_dw333_bwd_stats(const void* g, const void* a, const float* spartial, int stiles, int count,
                         const float* gamma, const float* save, float* dgamma, float* dbeta, const float* w,
-                        const float* x, const float* pre, int pre_act, float* out, float* wpartial, float* partial,
-                        int N, int C, int T, int H, int W, int strideHW, void* stream);
+                        const void* x, const float* pre, int pre_act, void* out, float* wpartial, float* partial,
+                        int N, int C, int T, int H, int W, int strideHW, int mx, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Stem (x3d.py:196-208,317-318): dense 1x3x3 s(1,2,2) 3->C, then depthwise temporal 5x1x1.

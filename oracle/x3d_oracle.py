@@ -158,18 +158,58 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
+class _StoreBf16(torch.autograd.Function):
+    """y = bf16(x) widened again (round to nearest even); the gradient passes unchanged."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _StoreGradBf16(torch.autograd.Function):
+    """Identity whose incoming gradient is rounded to bf16."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+# Mixed-storage mode of the product (NOT in the reference, whose tensors are all fp32; include/x3dhip.h X3D_MX_*,
+# BASELINE config 5 "bf16 storage / fp32 accumulate"): when True, the four wide tensors of every bottleneck are rounded
+# to bf16 where the product stores them -- conv1's and conv2's raw outputs in the forward pass, and the gradients with
+# respect to the two pre-activations (bn1's output; bn2's output after the SE gate) in the backward pass.  Everything
+# else, including all arithmetic, is the restatement of x3d.py above and below.  Tests set this flag around a call.
+BF16_WIDE = False
+
+
 def bottleneck(x, sd, p, stride, has_se, has_ds, S, training, new_stats):
     """x3d.py:143-171."""
     cm = sd[p + ".conv2.weight"].shape[0]
+    q = BF16_WIDE
     out = F.conv3d(x, sd[p + ".conv1.weight"])
-    out = torch.relu(split_bn(out, sd, p + ".bn1", S, training, new_stats))
+    if q:
+        out = _StoreBf16.apply(out)
+    out = split_bn(out, sd, p + ".bn1", S, training, new_stats)
+    if q:
+        out = _StoreGradBf16.apply(out)
+    out = torch.relu(out)
     out = F.conv3d(out, sd[p + ".conv2.weight"], stride=(1, stride, stride), padding=1, groups=cm)
+    if q:
+        out = _StoreBf16.apply(out)
     out = split_bn(out, sd, p + ".bn2", S, training, new_stats)
     if has_se:
         g = out.mean(dim=(2, 3, 4), keepdim=True)
         g = torch.relu(F.conv3d(g, sd[p + ".fc1.weight"], sd[p + ".fc1.bias"]))
         g = torch.sigmoid(F.conv3d(g, sd[p + ".fc2.weight"], sd[p + ".fc2.bias"]))
         out = out * g
+    if q:
+        out = _StoreGradBf16.apply(out)
     out = swish(out)
     out = F.conv3d(out, sd[p + ".conv3.weight"])
     out = split_bn(out, sd, p + ".bn3", S, training, new_stats)

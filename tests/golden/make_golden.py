@@ -59,7 +59,16 @@ def _grad_record(net, out, tag):
     return grads
 
 
-def train_case(ref, version, B, T, H, splits, seed=0, task="class"):
+def _ref_model(ref, version, **kw):
+    """The reference's generate_model (x3d.py:365-374).  'L' is not a key of the reference's tables (x3d.py:352-363):
+    SURVEY.md section 7 step 10 defines it as the XL depth at M widths, which the reference's own ResNet / Bottleneck
+    classes build when given those two table rows."""
+    if version == "L":
+        return ref.ResNet(ref.Bottleneck, ref.get_blocks("XL"), ref.get_inplanes("M"), **kw)
+    return ref.generate_model(version, **kw)
+
+
+def train_case(ref, version, B, T, H, splits, seed=0, task="class", second_draw_threads=0):
     """One training step of the reference in fp32 (the parity target) and in fp64 (the
     same reference code after .double(): the exact-arithmetic value, which measures how
     much of an fp32 discrepancy is the reference's own rounding noise)."""
@@ -69,7 +78,7 @@ def train_case(ref, version, B, T, H, splits, seed=0, task="class"):
     g32 = None
     for tag, dt in (("", torch.float32), ("64", torch.float64)):
         torch.manual_seed(0)
-        net = ref.generate_model(version, n_classes=400, dropout=0.0, base_bn_splits=splits, task=task)
+        net = _ref_model(ref, version, n_classes=400, dropout=0.0, base_bn_splits=splits, task=task)
         sd = synthetic.procedural_state_dict(net.state_dict(), seed)
         net.load_state_dict(sd)
         net = net.to(dt)
@@ -114,6 +123,27 @@ def train_case(ref, version, B, T, H, splits, seed=0, task="class"):
             with torch.no_grad():
                 out["eval_logits"] = net(x).numpy()[:, :, 0] if task == "class" else net(x).numpy()
         del net, logits, loss, grads
+    if second_draw_threads:
+        # A second fp32 run of the reference with another intra-op thread count (= another summation order in its
+        # convolutions and reductions): an independent draw of the reference's own fp32 rounding noise.  At the 55-block
+        # depth one draw under-estimates the floor (global gradient norm vs fp64: 3.0e-4 with 8 threads, 1.5e-3 with 1).
+        nt = torch.get_num_threads()
+        torch.set_num_threads(second_draw_threads)
+        torch.manual_seed(0)
+        net = _ref_model(ref, version, n_classes=400, dropout=0.0, base_bn_splits=splits, task=task)
+        net.load_state_dict(synthetic.procedural_state_dict(net.state_dict(), seed))
+        net.train(True)
+        logits = net(x)
+        loss = torch.nn.CrossEntropyLoss()(logits, y if task == "class" else y.expand(B, logits.shape[2]))
+        loss.backward()
+        rec = {}
+        _grad_record(net, rec, "")
+        out["grad_norms_draw2"] = rec["grad_norms"]
+        out["grad_global_norm_draw2"] = rec["grad_global_norm"]
+        out["grad_sketch_draw2"] = rec["grad_sketch"]
+        for k in FULL_GRADS:
+            out["grad_draw2/" + k] = rec["grad/" + k]
+        torch.set_num_threads(nt)
     return out
 
 
@@ -221,6 +251,8 @@ def main():
         jobs["train_M_16x16x224_s2"] = lambda: train_case(ref, "M", 16, 16, 224, 2)
     # X3D-XL widths (x3d.py:355) pinned by the reference itself on a tiny clip
     jobs["train_XL_2x4x64_s1"] = lambda: train_case(ref, "XL", 2, 4, 64, 1, seed=2)
+    # "X3D-L" (BASELINE config 5's architecture: XL depth, M widths) in fp32 -- the target of the mixed-storage (bf16) mode
+    jobs["train_L_4x4x96_s1"] = lambda: train_case(ref, "L", 4, 4, 96, 1, seed=3, second_draw_threads=1)
     for name, fn in jobs.items():
         if args.only and args.only != name:
             continue

@@ -46,6 +46,9 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
     # global norm
     gg = np.sqrt((got ** 2).sum())
     floor = abs(float(g["grad_global_norm"]) - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"])
+    two = "grad_global_norm_draw2" in g.files       # fixture with a second fp32 draw of the reference: floor = the larger
+    if two:
+        floor = max(floor, abs(float(g["grad_global_norm_draw2"]) - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"]))
     rep["global_norm_err"] = abs(gg - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"])
     rep["global_norm_floor"] = floor
     # the global norm averages the per-element rounding noise out (floor <= 4.6e-4 in every X3D-M fixture): BASELINE's
@@ -57,6 +60,8 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
     scale = n64 + 1e-6 * float(g["grad_global_norm64"])
     e_got = np.abs(got - n64) / scale
     e_ref = np.abs(n32 - n64) / scale
+    if two:
+        e_ref = np.maximum(e_ref, np.abs(g["grad_norms_draw2"] - n64) / scale)
     rep["norm_err_median"], rep["norm_floor_median"] = float(np.median(e_got)), float(np.median(e_ref))
     rep["norm_err_max"], rep["norm_floor_max"] = float(e_got.max()), float(e_ref.max())
     assert rep["norm_err_median"] <= rtol + 3 * rep["norm_floor_median"], rep
@@ -65,6 +70,8 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
     sk = sketch_fn(grads)
     rep["sketch_err"] = rel(sk, g["grad_sketch64"])
     rep["sketch_floor"] = rel(g["grad_sketch"], g["grad_sketch64"])
+    if two:
+        rep["sketch_floor"] = max(rep["sketch_floor"], rel(g["grad_sketch_draw2"], g["grad_sketch64"]))
     assert rep["sketch_err"] <= rtol + 3 * rep["sketch_floor"], rep
     # the small gradients shipped in full
     worst = 0.0
@@ -73,6 +80,8 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
             name = k[7:]
             e = rel(grads[name], g[k])
             f = rel(g["grad/" + name], g[k])
+            if two:
+                f = max(f, rel(g["grad_draw2/" + name], g[k]))
             worst = max(worst, e / (rtol + 3 * f))
             assert e <= rtol + 3 * f, (name, e, f)
     rep["full_grad_worst_ratio"] = worst

@@ -38,7 +38,7 @@ def test_state_dict_keys_match_reference(golden_dir):
 
 @pytest.mark.parametrize("case", ["train_M_2x4x32_s1", "train_M_8x4x64_s2", "train_M_16x2x47_s4",
                                   "train_M_2x4x111_s1", "train_M_2x4x158_s2", "train_M_2x8x112_s1",
-                                  "train_XL_2x4x64_s1"])          # XL widths (x3d.py:355) pinned by the reference itself
+                                  "train_XL_2x4x64_s1", "train_L_4x4x96_s1"])          # XL widths (x3d.py:355) pinned by the reference itself
 def test_train_step_matches_reference(golden_dir, case):
     g = _load(golden_dir, case)
     B, T, H, S = [int(v) for v in g["shape"]]

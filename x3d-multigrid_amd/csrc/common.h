@@ -69,6 +69,108 @@ __device__ __forceinline__ float act_bwd(float s, int act) {
     return 1.f;
 }
 
+// ---------------------------------------------------------------------------------------
+// Activation storage: fp32, or bf16 for the wide (Cmid) tensors of a bottleneck in the mixed-storage mode (BASELINE
+// config 5: bf16 storage / fp32 accumulate).  `bf` is a launch-uniform flag; `i` is the ELEMENT index.  Arithmetic is
+// always fp32: bf16 -> fp32 is a 16-bit shift, fp32 -> bf16 rounds to nearest even (v_cvt_pk_bf16_f32).
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) __bf16 x3d_bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 x3d_bf16x2;
+
+__device__ __forceinline__ float4 ldx4(const void* p, size_t i, int bf) {
+    if (bf) {
+        const x3d_bf16x4 v = *reinterpret_cast<const x3d_bf16x4*>(reinterpret_cast<const __bf16*>(p) + i);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ float2 ldx2(const void* p, size_t i, int bf) {
+    if (bf) {
+        const x3d_bf16x2 v = *reinterpret_cast<const x3d_bf16x2*>(reinterpret_cast<const __bf16*>(p) + i);
+        return make_float2((float)v[0], (float)v[1]);
+    }
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ float ldx1(const void* p, size_t i, int bf) {
+    if (bf) return (float)reinterpret_cast<const __bf16*>(p)[i];
+    return reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void stx4(void* p, size_t i, int bf, float a, float b, float c, float d) {
+    if (bf) {
+        x3d_bf16x4 v;
+        v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+        *reinterpret_cast<x3d_bf16x4*>(reinterpret_cast<__bf16*>(p) + i) = v;
+    } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = make_float4(a, b, c, d);
+    }
+}
+__device__ __forceinline__ void stx2(void* p, size_t i, int bf, float a, float b) {
+    if (bf) {
+        x3d_bf16x2 v;
+        v[0] = (__bf16)a; v[1] = (__bf16)b;
+        *reinterpret_cast<x3d_bf16x2*>(reinterpret_cast<__bf16*>(p) + i) = v;
+    } else {
+        *reinterpret_cast<float2*>(reinterpret_cast<float*>(p) + i) = make_float2(a, b);
+    }
+}
+__device__ __forceinline__ void stx1(void* p, size_t i, int bf, float a) {
+    if (bf) reinterpret_cast<__bf16*>(p)[i] = (__bf16)a;
+    else reinterpret_cast<float*>(p)[i] = a;
+}
+
+// What a consumer reads back from a tensor stored with flag `bf`: statistics that describe a stored tensor (BN sums, BN
+// backward sums) are taken from these values, so the BN that follows sees the statistics of the tensor it normalises.
+__device__ __forceinline__ float stored(float v, int bf) { return bf ? (float)(__bf16)v : v; }
+
+// The same with a wave-uniform base (SGPR pair, already advanced to the sample in BYTES: see mx_base) and a 32-bit
+// element offset (one VGPR): `global_load ... v_off, s[base]`.
+__device__ __forceinline__ const char* mx_base(const void* p, size_t elems, int bf) {
+    return reinterpret_cast<const char*>(p) + elems * (bf ? 2u : 4u);
+}
+__device__ __forceinline__ char* mx_base(void* p, size_t elems, int bf) {
+    return reinterpret_cast<char*>(p) + elems * (bf ? 2u : 4u);
+}
+__device__ __forceinline__ float4 ldo4(const char* base, unsigned eoff, int bf) {
+    if (bf) {
+        const x3d_bf16x4 v = *reinterpret_cast<const x3d_bf16x4*>(base + eoff * 2u);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+    return *reinterpret_cast<const float4*>(base + eoff * 4u);
+}
+__device__ __forceinline__ float2 ldo2(const char* base, unsigned eoff, int bf) {
+    if (bf) {
+        const x3d_bf16x2 v = *reinterpret_cast<const x3d_bf16x2*>(base + eoff * 2u);
+        return make_float2((float)v[0], (float)v[1]);
+    }
+    return *reinterpret_cast<const float2*>(base + eoff * 4u);
+}
+__device__ __forceinline__ float ldo1(const char* base, unsigned eoff, int bf) {
+    if (bf) return (float)*reinterpret_cast<const __bf16*>(base + eoff * 2u);
+    return *reinterpret_cast<const float*>(base + eoff * 4u);
+}
+__device__ __forceinline__ void sto4(char* base, unsigned eoff, int bf, float a, float b, float c, float d) {
+    if (bf) {
+        x3d_bf16x4 v;
+        v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+        *reinterpret_cast<x3d_bf16x4*>(base + eoff * 2u) = v;
+    } else {
+        *reinterpret_cast<float4*>(base + eoff * 4u) = make_float4(a, b, c, d);
+    }
+}
+__device__ __forceinline__ void sto2(char* base, unsigned eoff, int bf, float a, float b) {
+    if (bf) {
+        x3d_bf16x2 v;
+        v[0] = (__bf16)a; v[1] = (__bf16)b;
+        *reinterpret_cast<x3d_bf16x2*>(base + eoff * 2u) = v;
+    } else {
+        *reinterpret_cast<float2*>(base + eoff * 4u) = make_float2(a, b);
+    }
+}
+__device__ __forceinline__ void sto1(char* base, unsigned eoff, int bf, float a) {
+    if (bf) *reinterpret_cast<__bf16*>(base + eoff * 2u) = (__bf16)a;
+    else *reinterpret_cast<float*>(base + eoff * 4u) = a;
+}
+
 // Block-wide sum of `nval` per-thread values (nval <= 32) for 256-thread blocks.
 // red must hold 4*nval floats.  Result valid in thread 0..nval-1 (value index = threadIdx.x).
 template <int NVAL>

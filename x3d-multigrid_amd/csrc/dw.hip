@@ -115,14 +115,21 @@ __device__ __forceinline__ void make_chunks(const DwGeom& g, int n, int c0, int 
 // tensor / beyond T read element 0 of the sample) and masked when it is written to LDS.  A load
 // under a divergent branch makes the compiler drain vmcnt -- including the previous step's output
 // stores -- at the top of every T step.
-template <int NCH, bool VEC>
+// MX (mixed-storage build): `base` points at a bf16 array (the float* type is nominal); offsets are in elements.
+template <int NCH, bool VEC, bool MX>
 __device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chunk (&ch)[NCH], int toff, bool tvalid,
                                        float4 (&reg)[NCH]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const bool ok = tvalid && ch[i].goff >= 0;
         if (VEC) {
-            reg[i] = *reinterpret_cast<const float4*>(base + (ok ? ch[i].goff + toff : 0));
+            if (MX) reg[i] = ldx4(base, (size_t)(ok ? ch[i].goff + toff : 0), 1);
+            else reg[i] = *reinterpret_cast<const float4*>(base + (ok ? ch[i].goff + toff : 0));
+        } else if (MX) {
+            const int nv = ch[i].nval;
+            const unsigned o = ok ? (unsigned)(ch[i].goff + toff) : 0u;
+            reg[i] = make_float4(ldx1(base, o, 1), ldx1(base, o + (nv > 1 ? 1u : 0u), 1), ldx1(base, o + (nv > 2 ? 2u : 0u), 1),
+                                 ldx1(base, o + (nv > 3 ? 3u : 0u), 1));
         } else {
             // element offsets depend on the chunk only (hoisted out of the T march); a chunk that is not loaded reads
             // elements 0..3 of the sample (nval <= 4 <= the sample's size)
@@ -179,7 +186,7 @@ extern "C" int x3d_debug_dwtrace(void* dst, size_t bytes) { return (int)hipMemcp
 #define DTR(i) do { } while (0)
 #endif
 
-template <int NCH, int STRIDE, bool UNI, bool VEC>
+template <int NCH, int STRIDE, bool UNI, bool VEC, bool MX>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef X3D_TRACE
@@ -212,12 +219,12 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
 
     Chunk ch[NCH];
     make_chunks<NCH>(g, n, c0, h_in0, g.H, g.W, A.pre, ch);
-    const float* xb = A.x + (size_t)n * g.C * g.T * g.H * g.W;
+    const float* xb = reinterpret_cast<const float*>(mx_base(A.x, (size_t)n * g.C * g.T * g.H * g.W, MX));
     const int plane = g.H * g.W;
 
     float4 reg[NCH], reg1[NCH];
-    fetch4<NCH, VEC>(xb, ch, 0, true, reg);              // need addresses only: in flight during the statistics below
-    fetch4<NCH, VEC>(xb, ch, plane, g.T > 1, reg1);      // (planes 0 and 1 together: one round trip less)
+    fetch4<NCH, VEC, MX>(xb, ch, 0, true, reg);          // need addresses only: in flight during the statistics below
+    fetch4<NCH, VEC, MX>(xb, ch, plane, g.T > 1, reg1);  // (planes 0 and 1 together: one round trip less)
     if (A.sp != nullptr) {
         // BN finalize of this workgroup's channels for sample n's split (x3d.py:47-58): fp64 sums over N/S samples x
         // stiles partial pairs in a fixed order (identical in every workgroup of a (split, channel)); the tile-0
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     // fresh store; the store's ack then hides under the next step's stencil.
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
         if (t == 5) DTR(2);
-        fetch4<NCH, VEC>(xb, ch, (t + 2) * plane, t + 2 < g.T, reg);    // in flight during the stencil
+        fetch4<NCH, VEC, MX>(xb, ch, (t + 2) * plane, t + 2 < g.T, reg);    // in flight during the stencil
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
             read_plane(ring + (size_t)((t + 1) & 1) * g.slot, wc);
@@ -349,6 +356,10 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
 #pragma unroll
                 for (int i = 1; i < 4; ++i) if (wo + i >= g.Wo) o[i] = 0.f;
             }
+            if (MX) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = stored(o[i], 1);      // statistics of the tensor as stored
+            }
             s1 += (o[0] + o[1]) + (o[2] + o[3]);
             s2 = fmaf(o[0], o[0], fmaf(o[1], o[1], fmaf(o[2], o[2], fmaf(o[3], o[3], s2))));
         }
@@ -359,7 +370,15 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
         if (valid) {
             float* py = A.y + ybase + (size_t)t * g.Ho * g.Wo;
             const int wo = grp * 4;
-            if (VEC) {
+            if (MX) {
+                const size_t yi = ybase + (size_t)t * g.Ho * g.Wo;
+                if (VEC) {
+                    stx4(A.y, yi, 1, o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (wo + i < g.Wo) stx1(A.y, yi + i, 1, o[i]);
+                }
+            } else if (VEC) {
                 *reinterpret_cast<float4*>(py) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
                 py[0] = o[0];
@@ -442,7 +461,7 @@ __device__ __forceinline__ void store_dy(float* slot, const Chunk (&ch)[NCH], bo
     }
 }
 
-template <int NCH, int STRIDE, bool UNI, bool VEC>
+template <int NCH, int STRIDE, bool UNI, bool VEC, bool MX>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef X3D_TRACE
@@ -489,13 +508,13 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         }
     }
     const size_t vol_o = (size_t)n * g.C * g.T * g.Ho * g.Wo;
-    const float* gb = A.g + vol_o;
-    const float* ab = A.a + vol_o;
+    const float* gb = reinterpret_cast<const float*>(mx_base(A.g, vol_o, MX));
+    const float* ab = reinterpret_cast<const float*>(mx_base(A.a, vol_o, MX));
     const int plane_o = g.Ho * g.Wo;
 
     float4 rg[NCH], ra[NCH];
-    fetch4<NCH, VEC>(gb, ch, 0, true, rg);               // addresses only: in flight during the statistics below
-    fetch4<NCH, VEC>(ab, ch, 0, true, ra);
+    fetch4<NCH, VEC, MX>(gb, ch, 0, true, rg);           // addresses only: in flight during the statistics below
+    fetch4<NCH, VEC, MX>(ab, ch, 0, true, ra);
     if (A.cb == nullptr) {
         // BN backward finalize of this workgroup's channels (single split; x3d.py:47-58 backward): fp64 sums over all
         // samples x stiles partial pairs in a fixed order (identical in every workgroup of a channel); the (tile 0,
@@ -551,8 +570,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     }
     {
         float4 rg1[NCH], ra1[NCH];                       // plane 1 requested before plane 0 is staged: one round trip less
-        fetch4<NCH, VEC>(gb, ch, plane_o, g.T > 1, rg1);
-        fetch4<NCH, VEC>(ab, ch, plane_o, g.T > 1, ra1);
+        fetch4<NCH, VEC, MX>(gb, ch, plane_o, g.T > 1, rg1);
+        fetch4<NCH, VEC, MX>(ab, ch, plane_o, g.T > 1, ra1);
         store_dy<NCH, VEC>(ring, ch, true, k0, k1, k2, rg, ra);
         store_dy<NCH, VEC>(ring + g.slot, ch, g.T > 1, k0, k1, k2, rg1, ra1);
     }
@@ -605,7 +624,19 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     auto load_x = [&](int t) {
         const bool ok = valid && t < g.T;
         const float* px = A.x + (ok ? xbase + (size_t)t * g.H * g.W : 0);
-        if (VEC) {
+        if (MX) {
+            const size_t xi = ok ? xbase + (size_t)t * g.H * g.W : 0;
+            if (VEC) {
+                const float4 qv = ldx4(A.x, xi, 1);
+                xnext[0] = qv.x; xnext[1] = qv.y; xnext[2] = qv.z; xnext[3] = qv.w;
+            } else {
+                const int rem = g.W - w0;
+                xnext[0] = ldx1(A.x, xi, 1); xnext[1] = ldx1(A.x, xi + (rem > 1 ? 1 : 0), 1);
+                xnext[2] = ldx1(A.x, xi + (rem > 2 ? 2 : 0), 1); xnext[3] = ldx1(A.x, xi + (rem > 3 ? 3 : 0), 1);
+#pragma unroll
+                for (int i = 1; i < 4; ++i) xnext[i] = i < rem ? xnext[i] : 0.f;
+            }
+        } else if (VEC) {
             const float4 qv = *reinterpret_cast<const float4*>(px);
             xnext[0] = qv.x; xnext[1] = qv.y; xnext[2] = qv.z; xnext[3] = qv.w;
         } else {
@@ -620,8 +651,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     // window planes (wa, wb, wc) = dY planes (t-1, t, t+1); time tap kt uses plane t+1-kt
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
         if (t == 5) DTR(2);
-        fetch4<NCH, VEC>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, rg);
-        fetch4<NCH, VEC>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, ra);
+        fetch4<NCH, VEC, MX>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, rg);
+        fetch4<NCH, VEC, MX>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, ra);
         float xv[4] = {xnext[0], xnext[1], xnext[2], xnext[3]};      // loaded one step ago, complete since the last LDS staging
         load_x(t + 1);                                               // next step's raw input, in flight during the stencil
         float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -679,7 +710,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                o[i] = d[i] * dact[i];
+                o[i] = stored(d[i] * dact[i], MX);
                 s1 += o[i];
                 s2 = fmaf(o[i], xv[i], s2);
             }
@@ -690,7 +721,15 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         if (t == 5) DTR(4);
         if (valid) {
             float* po = A.out + xbase + (size_t)t * g.H * g.W;
-            if (VEC) {
+            if (MX) {
+                const size_t oi = xbase + (size_t)t * g.H * g.W;
+                if (VEC) {
+                    stx4(A.out, oi, 1, o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (w0 + i < g.W) stx1(A.out, oi + i, 1, o[i]);
+                }
+            } else if (VEC) {
                 *reinterpret_cast<float4*>(po) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
@@ -787,11 +826,12 @@ static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, h
     return X3D_OK;
 }
 
-#define DW_CASE(KERNEL, N_, S_)                                                                        \
-    (uni ? (vec ? dw_launch(KERNEL<N_, S_, true, true>, ARGS_, GEO_, LDSB_, s)                          \
-                : dw_launch(KERNEL<N_, S_, true, false>, ARGS_, GEO_, LDSB_, s))                        \
-         : (vec ? dw_launch(KERNEL<N_, S_, false, true>, ARGS_, GEO_, LDSB_, s)                         \
-                : dw_launch(KERNEL<N_, S_, false, false>, ARGS_, GEO_, LDSB_, s)))
+#define DW_CASE2(KERNEL, N_, S_, MX_)                                                                  \
+    (uni ? (vec ? dw_launch(KERNEL<N_, S_, true, true, MX_>, ARGS_, GEO_, LDSB_, s)                     \
+                : dw_launch(KERNEL<N_, S_, true, false, MX_>, ARGS_, GEO_, LDSB_, s))                   \
+         : (vec ? dw_launch(KERNEL<N_, S_, false, true, MX_>, ARGS_, GEO_, LDSB_, s)                    \
+                : dw_launch(KERNEL<N_, S_, false, false, MX_>, ARGS_, GEO_, LDSB_, s)))
+#define DW_CASE(KERNEL, N_, S_) (mx ? DW_CASE2(KERNEL, N_, S_, true) : DW_CASE2(KERNEL, N_, S_, false))
 
 #define DW_DISPATCH(KERNEL, ARGS, GEO, LDSB)                                                          \
     do {                                                                                               \
@@ -813,14 +853,19 @@ static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, h
         if (rc_ != X3D_OK) return rc_;                                                                 \
     } while (0)
 
-extern "C" int x3d_dw333_fwd(const float* x, const float* w, float* y, int N, int C, int T, int H, int W,
-                             int strideHW, const float* pre, int pre_act, float* partial, void* stream) {
+// mx of the channelwise entries: all of the call's activation tensors are bf16, or none
+#define DW_MX_FWD (X3D_MX_X | X3D_MX_Y)
+#define DW_MX_BWD (X3D_MX_GA | X3D_MX_X | X3D_MX_Y)
+
+extern "C" int x3d_dw333_fwd(const void* x, const float* w, void* y, int N, int C, int T, int H, int W,
+                             int strideHW, const float* pre, int pre_act, float* partial, int mx, void* stream) {
     X3D_CHECK_ARG(x && w && y);
+    X3D_CHECK_ARG(mx == 0 || mx == DW_MX_FWD);
     X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
     X3D_CHECK_ARG(pre_act == X3D_ACT_NONE || pre_act == X3D_ACT_RELU);     // x3d.py:147-150: ReLU precedes conv2
     DwFwdArgs A;
-    A.x = x; A.w = w; A.y = y; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE; A.partial = partial;
+    A.x = (const float*)x; A.w = w; A.y = (float*)y; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE; A.partial = partial;
     A.sp = nullptr; A.stiles = 0; A.S = 1; A.count = 0; A.gamma = A.beta = nullptr; A.rmean = A.rvar = nullptr;
     A.momentum = A.eps = 0.f; A.save = A.coef_out = nullptr;
     A.g = make_geom(N, C, T, H, W, strideHW, false);
@@ -832,18 +877,19 @@ extern "C" int x3d_dw333_fwd(const float* x, const float* w, float* y, int N, in
     return X3D_OK;
 }
 
-extern "C" int x3d_dw333_fwd_stats(const float* x, const float* w, float* y, int N, int C, int T, int H, int W,
+extern "C" int x3d_dw333_fwd_stats(const void* x, const float* w, void* y, int N, int C, int T, int H, int W,
                                    int strideHW, const float* spartial, int stiles, int S, int count,
                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    float momentum, float eps, float* save, float* coef_out, int pre_act,
-                                   float* partial, void* stream) {
+                                   float* partial, int mx, void* stream) {
     X3D_CHECK_ARG(x && w && y && spartial && gamma && beta && save && coef_out);
+    X3D_CHECK_ARG(mx == 0 || mx == DW_MX_FWD);
     X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0 && stiles > 0 && count > 0);
     X3D_CHECK_ARG(S > 0 && N % S == 0 && (strideHW == 1 || strideHW == 2));
     X3D_CHECK_ARG(pre_act == X3D_ACT_NONE || pre_act == X3D_ACT_RELU);     // x3d.py:147-150: ReLU precedes conv2
     X3D_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
     DwFwdArgs A;
-    A.x = x; A.w = w; A.y = y; A.pre = nullptr; A.pre_act = pre_act; A.partial = partial;
+    A.x = (const float*)x; A.w = w; A.y = (float*)y; A.pre = nullptr; A.pre_act = pre_act; A.partial = partial;
     A.g = make_geom(N, C, T, H, W, strideHW, false);
     A.sp = spartial; A.stiles = stiles; A.S = S; A.count = count; A.gamma = gamma; A.beta = beta;
     A.rmean = running_mean; A.rvar = running_var; A.momentum = momentum; A.eps = eps; A.save = save; A.coef_out = coef_out;
@@ -856,16 +902,18 @@ extern "C" int x3d_dw333_fwd_stats(const float* x, const float* w, float* y, int
     return X3D_OK;
 }
 
-extern "C" int x3d_dw333_bwd(const float* g, const float* a, const float* cb, const float* w, const float* x,
-                             const float* pre, int pre_act, float* out, float* wpartial, float* partial, int N,
-                             int C, int T, int H, int W, int strideHW, void* stream) {
+extern "C" int x3d_dw333_bwd(const void* g, const void* a, const float* cb, const float* w, const void* x,
+                             const float* pre, int pre_act, void* out, float* wpartial, float* partial, int N,
+                             int C, int T, int H, int W, int strideHW, int mx, void* stream) {
     X3D_CHECK_ARG(g && a && cb && w && x && out && wpartial);
+    X3D_CHECK_ARG(mx == 0 || mx == DW_MX_BWD);
     X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
     X3D_CHECK_ARG(pre_act == X3D_ACT_NONE || pre_act == X3D_ACT_RELU);     // x3d.py:147-150: ReLU precedes conv2
     DwBwdArgs A;
-    A.g = g; A.a = a; A.cb = cb; A.w = w; A.x = x; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE;
-    A.out = out; A.wpartial = wpartial; A.partial = partial;
+    A.g = (const float*)g; A.a = (const float*)a; A.cb = cb; A.w = w; A.x = (const float*)x; A.pre = pre;
+    A.pre_act = pre ? pre_act : X3D_ACT_NONE;
+    A.out = (float*)out; A.wpartial = wpartial; A.partial = partial;
     A.sp = nullptr; A.stiles = 0; A.count = 0; A.gamma = A.save = nullptr; A.dgamma = A.dbeta = nullptr;
     A.geo = make_geom(N, C, T, H, W, strideHW, true);
     const size_t ldsb = bwd_lds_bytes(A.geo);
@@ -876,17 +924,19 @@ extern "C" int x3d_dw333_bwd(const float* g, const float* a, const float* cb, co
     return X3D_OK;
 }
 
-extern "C" int x3d_dw333_bwd_stats(const float* g, const float* a, const float* spartial, int stiles, int count,
+extern "C" int x3d_dw333_bwd_stats(const void* g, const void* a, const float* spartial, int stiles, int count,
                                    const float* gamma, const float* save, float* dgamma, float* dbeta, const float* w,
-                                   const float* x, const float* pre, int pre_act, float* out, float* wpartial,
-                                   float* partial, int N, int C, int T, int H, int W, int strideHW, void* stream) {
+                                   const void* x, const float* pre, int pre_act, void* out, float* wpartial,
+                                   float* partial, int N, int C, int T, int H, int W, int strideHW, int mx, void* stream) {
     X3D_CHECK_ARG(g && a && spartial && gamma && save && dgamma && dbeta && w && x && out && wpartial);
+    X3D_CHECK_ARG(mx == 0 || mx == DW_MX_BWD);
     X3D_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0 && H > 0 && W > 0 && stiles > 0 && count > 0);
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
     X3D_CHECK_ARG(pre_act == X3D_ACT_NONE || pre_act == X3D_ACT_RELU);     // x3d.py:147-150: ReLU precedes conv2
     DwBwdArgs A;
-    A.g = g; A.a = a; A.cb = nullptr; A.w = w; A.x = x; A.pre = pre; A.pre_act = pre ? pre_act : X3D_ACT_NONE;
-    A.out = out; A.wpartial = wpartial; A.partial = partial;
+    A.g = (const float*)g; A.a = (const float*)a; A.cb = nullptr; A.w = w; A.x = (const float*)x; A.pre = pre;
+    A.pre_act = pre ? pre_act : X3D_ACT_NONE;
+    A.out = (float*)out; A.wpartial = wpartial; A.partial = partial;
     A.sp = spartial; A.stiles = stiles; A.count = count; A.gamma = gamma; A.save = save; A.dgamma = dgamma; A.dbeta = dbeta;
     A.geo = make_geom(N, C, T, H, W, strideHW, true);
     X3D_CHECK_ARG(A.geo.cpb <= 16);

@@ -24,16 +24,16 @@
 // pw6.hip: forward kernel of the large-channel layers (whole-K items, 3-term split-bf16 MFMA)
 bool x3d_pw6_ok(int K, int M, int P);
 int x3d_pw6_tiles(int P);
-int x3d_pw6_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M,
-                   int P, int in_act, hipStream_t s);
+int x3d_pw6_launch(const void* x, const float* cin, const float* wp, void* y, float* partial, int N, int K, int M,
+                   int P, int in_act, int x_bf, int y_bf, hipStream_t s);
 bool x3d_pwfs_ok(int K, int M, int P);
 int x3d_pwfs_tiles(int N, int P);
-int x3d_pwfs_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M, int P,
-                    int in_act, hipStream_t s);
-bool x3d_pw7_ok(int K, int M, int P);
-int x3d_pw7_launch(const float* g, const float* a, const float* cb, const float* wpt, float* out, float* partial, int mode,
-                   const float* ex, const float* emask, const float* ecoef, int e_act, const float* addend,
-                   int addend_stride, int N, int K, int M, int T, int H, int W, hipStream_t s);
+int x3d_pwfs_launch(const void* x, const float* cin, const float* wp, void* y, float* partial, int N, int K, int M, int P,
+                    int in_act, int x_bf, int y_bf, hipStream_t s);
+bool x3d_pw7_ok(int K, int M, int P, int mx);
+int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* wpt, void* out, float* partial, int mode,
+                   const void* ex, const float* emask, const float* ecoef, int e_act, const float* addend,
+                   int addend_stride, int N, int K, int M, int T, int H, int W, int ga_bf, int y_bf, int ex_bf, hipStream_t s);
 
 namespace {
 
@@ -68,6 +68,10 @@ struct PwArgs {
     const float* addend;  // EPI_PLAIN / EPI_ACTBWD (may be NULL)
     int addend_stride;
     int mblocks, mt_run;  // M blocks per voxel tile; 16-row tiles per block actually used
+    // mixed-storage mode (kernels built with MX only; the pointers above are then bf16 arrays behind a float* type):
+    int x_bf;             // x (and a) are bf16
+    int y_bf;             // y is bf16
+    int ex_bf;            // ex is bf16
 };
 
 // NT consecutive voxels per lane: NT = 4 -> float4 loads/stores (needs P % 4 == 0, dense input),
@@ -89,6 +93,31 @@ template <int NT>
 __device__ __forceinline__ void vstore(float* p, const float (&v)[NT]) {
     if (NT == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % NT], v[2 % NT], v[3 % NT]);
     else p[0] = v[0];
+}
+
+// mixed-storage forms: wave-uniform byte base + element offset, or pointer + element index
+template <int NT>
+__device__ __forceinline__ void vloado(const char* base, unsigned eoff, int bf, float (&v)[NT]) {
+    if (NT == 4) {
+        const float4 t = ldo4(base, eoff, bf);
+        v[0] = t.x; v[1 % NT] = t.y; v[2 % NT] = t.z; v[3 % NT] = t.w;
+    } else {
+        v[0] = ldo1(base, eoff, bf);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void vloadx(const void* p, size_t i, int bf, float (&v)[NT]) {
+    if (NT == 4) {
+        const float4 t = ldx4(p, i, bf);
+        v[0] = t.x; v[1 % NT] = t.y; v[2 % NT] = t.z; v[3 % NT] = t.w;
+    } else {
+        v[0] = ldx1(p, i, bf);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void vstorex(void* p, size_t i, int bf, const float (&v)[NT]) {
+    if (NT == 4) stx4(p, i, bf, v[0], v[1 % NT], v[2 % NT], v[3 % NT]);
+    else stx1(p, i, bf, v[0]);
 }
 
 template <int MT, int NT, int IN, int EPI>
@@ -336,8 +365,9 @@ __global__ __launch_bounds__(256, 2) void pw_kernel(const PwArgs A) {
 // Channels >= K meet zero-padded weights and voxels >= P are never stored, so no load needs a
 // predicate -- addresses are only clamped into the tensor.
 // ---------------------------------------------------------------------------------------
-template <int MT, int NT, int IN, int EPI>
+template <int MT, int NT, int IN, int EPI, bool MX>
 __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
+    const int x_bf = MX ? A.x_bf : 0, y_bf = MX ? A.y_bf : 0, ex_bf = MX ? A.ex_bf : 0;      // fp32 build: folded away
     __shared__ float red[4 * MT * 16 * 2];
     __shared__ float Cl[(IN == IN_RAW) ? 4 : 3 * PW_MAXK];
     constexpr int NC = (IN == IN_BNBWD) ? 3 : 2;
@@ -369,8 +399,10 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* xrow = A.x + (size_t)n * K * (size_t)A.Pin + off;
-    const float* arow = (IN == IN_BNBWD) ? A.a + (size_t)n * K * (size_t)P + off : nullptr;
+    // per-sample bases are wave uniform; a sample's rows are < 2^32 elements away
+    const char* xs = mx_base(A.x, (size_t)n * K * (size_t)A.Pin, x_bf);
+    const char* as = (IN == IN_BNBWD) ? mx_base(A.a, (size_t)n * K * (size_t)P, x_bf) : nullptr;
+    const unsigned Pin32 = (unsigned)A.Pin;
     const float* wpl[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -385,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = min(16 * s + 4 * q + e, K - 1);
-            vload<NT>(xrow + (size_t)k * (size_t)A.Pin, xd[e]);
-            if (IN == IN_BNBWD) vload<NT>(arow + (size_t)k * (size_t)P, ad[e]);
+            vloado<NT>(xs, (unsigned)k * Pin32 + (unsigned)off, x_bf, xd[e]);
+            if (IN == IN_BNBWD) vloado<NT>(as, (unsigned)k * (unsigned)P + (unsigned)off, x_bf, ad[e]);
         }
     };
 
@@ -469,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
                     const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
                     esc[e] = c2.x; esh[e] = c2.y;
                 }
-                if (EPI_HAS_X(EPI)) vload<NT>(A.ex + mrow * (size_t)P + pc, xv[e]);
+                if (EPI_HAS_X(EPI)) vloadx<NT>(A.ex, mrow * (size_t)P + pc, EPI == EPI_ACTBWD ? ex_bf : 0, xv[e]);
                 if (EPI == EPI_RESBWD) vload<NT>(A.emask + mrow * (size_t)P + pc, mk[e]);
                 if (has_add) {
                     const float* pa = A.addend + mrow * (size_t)addP;
@@ -500,14 +532,15 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
                         const float xj = pv ? xv[e][j] : 0.f;
                         if (EPI == EPI_RESBWD) v[j] = (pv && mk[e][j] > 0.f) ? v[j] : 0.f;
                         else v[j] = pv ? v[j] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                        v[j] = stored(v[j], y_bf);
                         s1 += v[j];
                         s2 = fmaf(v[j], xj, s2);
                     }
                 } else if (EPI == EPI_STATS) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) { v[j] = pv ? v[j] : 0.f; s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+                    for (int j = 0; j < NT; ++j) { v[j] = stored(pv ? v[j] : 0.f, y_bf); s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
                 }
-                if (mv && pv) vstore<NT>(A.y + ((size_t)n * A.M + m) * (size_t)P + p0, v);
+                if (mv && pv) vstorex<NT>(A.y, ((size_t)n * A.M + m) * (size_t)P + p0, y_bf, v);
                 if (EPI != EPI_PLAIN) {
                     s1 = row16_sum(s1);
                     s2 = row16_sum(s2);
@@ -1544,6 +1577,21 @@ int launch_pw(PwArgs& A, hipStream_t s) {
     const bool dense = !A.strided && (A.Pin % 4 == 0);
     pw_plan(A.N, A.K, A.M, A.P, dense, &variant, &A.tiles, &A.mblocks, &A.mt_run);
     dim3 grid(cdiv(A.tiles, 8) * 8 * A.mblocks, A.N), block(256);
+    // mixed storage: only the packed streaming kernel (pw3) of this file reads / writes bf16 tensors
+    const bool mx = A.x_bf || A.y_bf || A.ex_bf;
+    if (mx && variant == 2 && A.wp != nullptr) {
+        // large-channel layers whose voxel count is not a multiple of 4 (odd clip sizes): the streaming kernel on the same
+        // 64-voxel tiles, as in the "no packed weights" case below
+        variant = 1;
+        const int mtiles = cdiv(A.M, 16);
+        A.mblocks = cdiv(mtiles, 4);
+        A.mt_run = cdiv(mtiles, A.mblocks);
+        grid = dim3(cdiv(A.tiles, 8) * 8 * A.mblocks, A.N);
+    }
+    if (mx && !(variant <= 1 && A.wp != nullptr && A.K <= PW_MAXK)) {
+        x3d_set_error("pw: no mixed-storage kernel for K=%d M=%d P=%d (packed=%d)", A.K, A.M, A.P, A.wp != nullptr);
+        return X3D_EINVAL;
+    }
     if (variant == 3 && A.wp != nullptr) {
         const int items = cdiv(A.tiles * A.N, 8) * 8 * A.mblocks;
         static const int pg_max = getenv("X3D_PW_PGRID") ? atoi(getenv("X3D_PW_PGRID")) : 512;
@@ -1582,13 +1630,17 @@ int launch_pw(PwArgs& A, hipStream_t s) {
             else hipLaunchKernelGGL((pw2_kernel<IN, EPI, false, false>), grid, block, 0, s, A);
         }
     } else if (A.wp != nullptr && A.K <= PW_MAXK) {
+#define PW3_GO(MT_, NT_)                                                                                    \
+    do {                                                                                                    \
+        if (mx) hipLaunchKernelGGL((pw3_kernel<MT_, NT_, IN, EPI, true>), grid, block, 0, s, A);             \
+        else hipLaunchKernelGGL((pw3_kernel<MT_, NT_, IN, EPI, false>), grid, block, 0, s, A);               \
+    } while (0)
         if (A.mt_run <= 2) {
-            if (variant == 0) hipLaunchKernelGGL((pw3_kernel<2, 4, IN, EPI>), grid, block, 0, s, A);
-            else hipLaunchKernelGGL((pw3_kernel<2, 1, IN, EPI>), grid, block, 0, s, A);
+            if (variant == 0) PW3_GO(2, 4); else PW3_GO(2, 1);
         } else {
-            if (variant == 0) hipLaunchKernelGGL((pw3_kernel<4, 4, IN, EPI>), grid, block, 0, s, A);
-            else hipLaunchKernelGGL((pw3_kernel<4, 1, IN, EPI>), grid, block, 0, s, A);
+            if (variant == 0) PW3_GO(4, 4); else PW3_GO(4, 1);
         }
+#undef PW3_GO
     } else if (A.mt_run <= 2) {
         if (variant == 0) hipLaunchKernelGGL((pw_kernel<2, 4, IN, EPI>), grid, block, 0, s, A);
         else hipLaunchKernelGGL((pw_kernel<2, 1, IN, EPI>), grid, block, 0, s, A);
@@ -1620,10 +1672,12 @@ struct WgArgs {
     int N, Ci, Co, P; long long Pin;
     int strided, T, H, W, Ho, Wo;
     int groups, units_per_sample, cob, cib, ct_run, it_run;
+    int ga_bf, x_bf;                                       // mixed-storage builds (MX) of the split-bf16 kernels: g and a / x are bf16 arrays
 };
 
-template <int CT, int IT, bool VEC>
+template <int CT, int IT, bool VEC, bool MX>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs A) {
+    const int ga_bf = MX ? A.ga_bf : 0, x_bf = MX ? A.x_bf : 0;
     __shared__ float red[4 * IT * 4 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
@@ -1661,15 +1715,15 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs A) {
             if (i < ct_run) {
                 const size_t rowb = ((size_t)n * A.Co + co[i]) * (size_t)P;
                 if (VEC) {
-                    ng[i] = *reinterpret_cast<const float4*>(A.g + rowb + pc);
-                    na[i] = *reinterpret_cast<const float4*>(A.a + rowb + pc);
+                    ng[i] = ldx4(A.g, rowb + pc, ga_bf);
+                    na[i] = ldx4(A.a, rowb + pc, ga_bf);
                 } else {
                     float tg[4], ta[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int pe = min(p + e, P - 1);
-                        tg[e] = A.g[rowb + pe];
-                        ta[e] = A.a[rowb + pe];
+                        tg[e] = ldx1(A.g, rowb + pe, ga_bf);
+                        ta[e] = ldx1(A.a, rowb + pe, ga_bf);
                     }
                     ng[i] = make_float4(tg[0], tg[1], tg[2], tg[3]);
                     na[i] = make_float4(ta[0], ta[1], ta[2], ta[3]);
@@ -1679,9 +1733,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs A) {
 #pragma unroll
         for (int j = 0; j < IT; ++j) {
             if (j < it_run) {
-                const float* px = A.x + ((size_t)n * A.Ci + ci[j]) * (size_t)A.Pin;
+                const size_t xrow = ((size_t)n * A.Ci + ci[j]) * (size_t)A.Pin;
                 if (VEC) {
-                    nx[j] = *reinterpret_cast<const float4*>(px + pc);
+                    nx[j] = ldx4(A.x, xrow + pc, x_bf);
                 } else {
                     float tx[4];
 #pragma unroll
@@ -1694,7 +1748,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs A) {
                             const int ho = rem / A.Wo, wo = rem - ho * A.Wo;
                             off = (size_t)(t * A.H + 2 * ho) * A.W + 2 * wo;
                         }
-                        tx[e] = px[off];
+                        tx[e] = ldx1(A.x, xrow + off, x_bf);
                     }
                     nx[j] = make_float4(tx[0], tx[1], tx[2], tx[3]);
                 }
@@ -1961,8 +2015,9 @@ __device__ __forceinline__ void split_bf16x4(const float (&v)[4], bf16x4& hi, bf
 // 32-column variants for the narrow ones (stages 1-2) so that padding rows are not staged for nothing.
 // GATHER: the input of a stride-(1,2,2) convolution (the downsample branch): its four voxels per slot are read at
 // (t, 2 ho, 2 wo) of the full-resolution input instead of as one float4.
-template <int CO, int CI, bool GATHER>
+template <int CO, int CI, bool GATHER, bool MX>
 __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, const int blk) {
+    const int ga_bf = MX ? A.ga_bf : 0, x_bf = (MX && !GATHER) ? A.x_bf : 0;
     constexpr int ND = CO / 16, NX = CI / 16;            // staged float4 slots per thread (dY, input)
     constexpr int MW = CO / 64, NW = CI / 16;            // 16x16 tiles per wave: MW (dY) x NW (input)
     __shared__ __attribute__((aligned(16))) __bf16 Dh[CO * W3_LD];
@@ -1992,8 +2047,8 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
         for (int i = 0; i < ND; ++i) {
             const int co = min(co0 + row0 + 16 * i, A.Co - 1);
             const size_t base = ((size_t)n * A.Co + co) * (size_t)P + pc;
-            rg[i] = *reinterpret_cast<const float4*>(A.g + base);
-            ra[i] = *reinterpret_cast<const float4*>(A.a + base);
+            rg[i] = ldx4(A.g, base, ga_bf);
+            ra[i] = ldx4(A.a, base, ga_bf);
             const float* cb = A.cb + ((size_t)n * A.Co + co) * 3;
             k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
         }
@@ -2013,7 +2068,7 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
             const int ci = min(ci0 + row0 + 16 * i, A.Ci - 1);
             const float* px = A.x + ((size_t)n * A.Ci + ci) * (size_t)A.Pin;
             if (GATHER) rx[i] = make_float4(px[goff[0]], px[goff[1]], px[goff[2]], px[goff[3]]);
-            else rx[i] = *reinterpret_cast<const float4*>(px + pc);
+            else rx[i] = ldx4(A.x, ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc, x_bf);
             if (A.pre != nullptr) {
                 const float2 p2 = *reinterpret_cast<const float2*>(A.pre + ((size_t)n * A.Ci + ci) * 2);
                 sc[i] = p2.x; sh[i] = p2.y;
@@ -2118,8 +2173,9 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
 // instead of once per 128 x 64 block (4 blocks at stage 3, 12 at stage 4: the batched launches fetched 2.2x their
 // algorithmic bytes, profiles/r02/a_traffic.json, and split the same values four times).  Waves form a 4 (dY) x 2 (input)
 // grid: MW x NW sixteen-row tiles per wave keep the LDS fragment reads per MFMA at the 128 x 64 kernel's level.
-template <int CO, int CI>
+template <int CO, int CI, bool MX>
 __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, const int blk) {
+    const int ga_bf = MX ? A.ga_bf : 0, x_bf = MX ? A.x_bf : 0;
     constexpr int NT = 512, RP = NT / 16;                // 32 rows staged per pass
     constexpr int ND = CO / RP, NX = CI / RP;
     constexpr int WCO = 4, WCI = 2;
@@ -2152,15 +2208,15 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
         for (int i = 0; i < ND; ++i) {
             const int co = min(co0 + row0 + RP * i, A.Co - 1);
             const size_t base = ((size_t)n * A.Co + co) * (size_t)P + pc;
-            rg[i] = *reinterpret_cast<const float4*>(A.g + base);
-            ra[i] = *reinterpret_cast<const float4*>(A.a + base);
+            rg[i] = ldx4(A.g, base, ga_bf);
+            ra[i] = ldx4(A.a, base, ga_bf);
             const float* cb = A.cb + ((size_t)n * A.Co + co) * 3;
             k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int ci = min(ci0 + row0 + RP * i, A.Ci - 1);
-            rx[i] = *reinterpret_cast<const float4*>(A.x + ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc);
+            rx[i] = ldx4(A.x, ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc, x_bf);
             if (A.pre != nullptr) {
                 const float2 p2 = *reinterpret_cast<const float2*>(A.pre + ((size_t)n * A.Ci + ci) * 2);
                 sc[i] = p2.x; sh[i] = p2.y;
@@ -2258,12 +2314,12 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
 }
 
 struct WgBatch;
-template <int CO, int CI>
+template <int CO, int CI, bool MX>
 __global__ __launch_bounds__(512, 2) void pw_wgrad4_batch_kernel(const WgBatch B);
 
-template <int CO, int CI, bool GATHER>
+template <int CO, int CI, bool GATHER, bool MX>
 __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
-    wgrad3_body<CO, CI, GATHER>(A, blockIdx.x, blockIdx.y);
+    wgrad3_body<CO, CI, GATHER, MX>(A, blockIdx.x, blockIdx.y);
 }
 
 // Every weight gradient of a backward pass that uses the same tile variant in one launch (up to WB_MAX jobs, passed by
@@ -2278,22 +2334,22 @@ struct WgBatch {
     int njobs;
 };
 
-template <int CO, int CI>
+template <int CO, int CI, bool MX>
 __global__ __launch_bounds__(512, 2) void pw_wgrad4_batch_kernel(const WgBatch B) {
     int j = 0;
     while (j + 1 < B.njobs && (int)blockIdx.x >= B.wg0[j + 1]) ++j;
     const int local = (int)blockIdx.x - B.wg0[j];
     const int groups = B.job[j].groups;
-    wgrad4_body<CO, CI>(B.job[j], local % groups, local / groups);
+    wgrad4_body<CO, CI, MX>(B.job[j], local % groups, local / groups);
 }
 
-template <int CO, int CI, bool GATHER>
+template <int CO, int CI, bool GATHER, bool MX>
 __global__ __launch_bounds__(256, 2) void pw_wgrad3_batch_kernel(const WgBatch B) {
     int j = 0;
     while (j + 1 < B.njobs && (int)blockIdx.x >= B.wg0[j + 1]) ++j;
     const int local = (int)blockIdx.x - B.wg0[j];
     const int groups = B.job[j].groups;
-    wgrad3_body<CO, CI, GATHER>(B.job[j], local % groups, local / groups);
+    wgrad3_body<CO, CI, GATHER, MX>(B.job[j], local % groups, local / groups);
 }
 
 static bool wgrad2_ok(int P, long long Pin, int Co, int Ci, bool strided) {
@@ -2446,8 +2502,8 @@ extern "C" int x3d_pw_fwd_tiles(int N, int Cin, int Cout, int P, int dense, int 
 }
 
 // tiles of the data gradient's `partial` (Cout = its K, Cin = its M)
-extern "C" int x3d_pw_bwd_tiles(int N, int Cin, int Cout, int P, int packed) {
-    if (packed && x3d_pw7_ok(Cout, Cin, P)) return x3d_pw6_tiles(P);
+extern "C" int x3d_pw_bwd_tiles(int N, int Cin, int Cout, int P, int packed, int mx) {
+    if (packed && x3d_pw7_ok(Cout, Cin, P, mx)) return x3d_pw6_tiles(P);
     return x3d_pw_tiles(N, Cout, Cin, P, 1);
 }
 
@@ -2479,69 +2535,79 @@ extern "C" int x3d_pw_pack_batch(const void* jobs, const int* wg_job, int n_work
     return X3D_OK;
 }
 
-extern "C" int x3d_pw_fwd(const float* x, const float* w, const float* wpacked, float* y, int N, int Cin, int Cout,
-                          int T, int H, int W, int strideHW, const float* pre, int pre_act, float* partial,
+extern "C" int x3d_pw_fwd(const void* x, const float* w, const float* wpacked, void* y, int N, int Cin, int Cout,
+                          int T, int H, int W, int strideHW, const float* pre, int pre_act, float* partial, int mx,
                           void* stream) {
     X3D_CHECK_ARG(x && w && y);
+    X3D_CHECK_ARG((mx & ~(X3D_MX_X | X3D_MX_Y)) == 0);
+    const int x_bf = (mx & X3D_MX_X) != 0, y_bf = (mx & X3D_MX_Y) != 0;
     X3D_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
     X3D_CHECK_ARG(N <= 65535);
     PwArgs A = {};
     const int Ho = strideHW == 2 ? (H - 1) / 2 + 1 : H, Wo = strideHW == 2 ? (W - 1) / 2 + 1 : W;
-    A.x = x; A.a = nullptr; A.cin = pre; A.w = w; A.wp = wpacked; A.w_ldk = 1; A.w_ldm = Cin; A.y = y;
+    A.x = (const float*)x; A.a = nullptr; A.cin = pre; A.w = w; A.wp = wpacked; A.w_ldk = 1; A.w_ldm = Cin; A.y = (float*)y;
+    A.x_bf = x_bf; A.y_bf = y_bf;
     A.N = N; A.K = Cin; A.M = Cout; A.P = T * Ho * Wo; A.Pin = (long long)T * H * W;
     A.in_act = pre_act; A.strided = strideHW == 2; A.T = T; A.H = H; A.W = W; A.Ho = Ho; A.Wo = Wo;
     A.partial = partial; A.addend = nullptr; A.addend_stride = 1;
     hipStream_t s = (hipStream_t)stream;
     if (wpacked != nullptr && strideHW == 1 && x3d_pw6_ok(Cin, Cout, A.P))
-        return x3d_pw6_launch(x, pre, wpacked, y, partial, N, Cin, Cout, A.P, pre_act, s);
+        return x3d_pw6_launch(x, pre, wpacked, y, partial, N, Cin, Cout, A.P, pre_act, x_bf, y_bf, s);
     if (wpacked != nullptr && strideHW == 1 && x3d_pwfs_ok(Cin, Cout, A.P))
-        return x3d_pwfs_launch(x, pre, wpacked, y, partial, N, Cin, Cout, A.P, pre_act, s);
+        return x3d_pwfs_launch(x, pre, wpacked, y, partial, N, Cin, Cout, A.P, pre_act, x_bf, y_bf, s);
     if (pre) return launch_pw<IN_AFFACT, EPI_STATS>(A, s);
     return launch_pw<IN_RAW, EPI_STATS>(A, s);
 }
 
-extern "C" int x3d_pw_bwd_data(const float* g, const float* a, const float* cb, const float* w,
-                               const float* wpacked_t, float* out,
-                               int N, int Cin, int Cout, int T, int H, int W, const float* x,
+extern "C" int x3d_pw_bwd_data(const void* g, const void* a, const float* cb, const float* w,
+                               const float* wpacked_t, void* out,
+                               int N, int Cin, int Cout, int T, int H, int W, const void* x,
                                const float* pre, int pre_act, const float* addend, int addend_stride,
-                               float* partial, void* stream) {
+                               float* partial, int mx, void* stream) {
     X3D_CHECK_ARG(g && a && cb && w && out);
+    X3D_CHECK_ARG((mx & ~(X3D_MX_X | X3D_MX_Y | X3D_MX_GA)) == 0);
+    const int ga_bf = (mx & X3D_MX_GA) != 0, y_bf = (mx & X3D_MX_Y) != 0, ex_bf = (mx & X3D_MX_X) != 0 && pre != nullptr;
     X3D_CHECK_ARG(N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(addend_stride == 1 || addend_stride == 2);
     X3D_CHECK_ARG((pre == nullptr) || (x != nullptr));
     PwArgs A = {};
-    A.x = g; A.a = a; A.cin = cb; A.w = w; A.wp = wpacked_t; A.w_ldk = Cin; A.w_ldm = 1; A.y = out;
+    A.x = (const float*)g; A.a = (const float*)a; A.cin = cb; A.w = w; A.wp = wpacked_t; A.w_ldk = Cin; A.w_ldm = 1;
+    A.y = (float*)out;
     A.N = N; A.K = Cout; A.M = Cin; A.P = T * H * W; A.Pin = A.P;
     A.strided = 0; A.T = T; A.H = H; A.W = W;
     A.Ho = (H - 1) / 2 + 1; A.Wo = (W - 1) / 2 + 1;
-    A.partial = partial; A.ex = x; A.ecoef = pre; A.e_act = pre_act;
+    A.partial = partial; A.ex = (const float*)x; A.ecoef = pre; A.e_act = pre_act;
+    A.x_bf = ga_bf; A.y_bf = y_bf; A.ex_bf = ex_bf;
     A.addend = addend; A.addend_stride = addend_stride;
     hipStream_t s = (hipStream_t)stream;
-    if (wpacked_t != nullptr && x3d_pw7_ok(Cout, Cin, A.P))
+    if (wpacked_t != nullptr && x3d_pw7_ok(Cout, Cin, A.P, mx))
         return x3d_pw7_launch(g, a, cb, wpacked_t, out, partial, pre ? 1 : 0, x, nullptr, pre, pre_act, addend, addend_stride,
-                              N, Cout, Cin, T, H, W, s);
+                              N, Cout, Cin, T, H, W, ga_bf, y_bf, ex_bf, s);
     if (pre) return launch_pw<IN_BNBWD, EPI_ACTBWD>(A, s);
     return launch_pw<IN_BNBWD, EPI_PLAIN>(A, s);
 }
 
-extern "C" int x3d_pw_bwd_data_res(const float* g, const float* a, const float* cb, const float* w,
+extern "C" int x3d_pw_bwd_data_res(const void* g, const void* a, const float* cb, const float* w,
                                    const float* wpacked_t, float* out, int N, int Cin, int Cout, int T, int H, int W,
                                    const float* res_out, const float* res_raw, const float* addend, int addend_stride,
-                                   float* partial, void* stream) {
+                                   float* partial, int mx, void* stream) {
     X3D_CHECK_ARG(g && a && cb && w && out && res_out && res_raw && partial);
+    X3D_CHECK_ARG((mx & ~X3D_MX_GA) == 0);
+    const int ga_bf = (mx & X3D_MX_GA) != 0;
     X3D_CHECK_ARG(N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(addend_stride == 1 || addend_stride == 2);
     PwArgs A = {};
-    A.x = g; A.a = a; A.cin = cb; A.w = w; A.wp = wpacked_t; A.w_ldk = Cin; A.w_ldm = 1; A.y = out;
+    A.x = (const float*)g; A.a = (const float*)a; A.cin = cb; A.w = w; A.wp = wpacked_t; A.w_ldk = Cin; A.w_ldm = 1; A.y = out;
+    A.x_bf = ga_bf;
     A.N = N; A.K = Cout; A.M = Cin; A.P = T * H * W; A.Pin = A.P;
     A.strided = 0; A.T = T; A.H = H; A.W = W;
     A.Ho = (H - 1) / 2 + 1; A.Wo = (W - 1) / 2 + 1;
     A.partial = partial; A.ex = res_raw; A.emask = res_out; A.ecoef = nullptr; A.e_act = X3D_ACT_RELU;
     A.addend = addend; A.addend_stride = addend_stride;
-    if (wpacked_t != nullptr && x3d_pw7_ok(Cout, Cin, A.P))
+    if (wpacked_t != nullptr && x3d_pw7_ok(Cout, Cin, A.P, mx))
         return x3d_pw7_launch(g, a, cb, wpacked_t, out, partial, 2, res_raw, res_out, nullptr, X3D_ACT_RELU, addend,
-                              addend_stride, N, Cout, Cin, T, H, W, (hipStream_t)stream);
+                              addend_stride, N, Cout, Cin, T, H, W, ga_bf, 0, 0, (hipStream_t)stream);
     return launch_pw<IN_BNBWD, EPI_RESBWD>(A, (hipStream_t)stream);
 }
 
@@ -2551,15 +2617,17 @@ extern "C" int x3d_pw_wgrad_groups(int N, int P, int Cout, int Cin, int strideHW
     return g;
 }
 
-extern "C" int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb, const float* x,
+extern "C" int x3d_pw_bwd_weight(const void* g, const void* a, const float* cb, const void* x,
                                  const float* pre, int pre_act, float* wpartial, int N, int Cin, int Cout,
-                                 int T, int H, int W, int strideHW, void* stream) {
+                                 int T, int H, int W, int strideHW, int mx, void* stream) {
     X3D_CHECK_ARG(g && a && cb && x && wpartial);
+    X3D_CHECK_ARG((mx & ~(X3D_MX_GA | X3D_MX_X)) == 0);
     X3D_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(strideHW == 1 || strideHW == 2);
     WgArgs A = {};
     const int Ho = strideHW == 2 ? (H - 1) / 2 + 1 : H, Wo = strideHW == 2 ? (W - 1) / 2 + 1 : W;
-    A.g = g; A.a = a; A.cb = cb; A.x = x; A.pre = pre; A.pre_act = pre_act; A.wpartial = wpartial;
+    A.g = (const float*)g; A.a = (const float*)a; A.cb = cb; A.x = (const float*)x; A.pre = pre; A.pre_act = pre_act;
+    A.wpartial = wpartial; A.ga_bf = (mx & X3D_MX_GA) != 0; A.x_bf = (mx & X3D_MX_X) != 0;
     A.N = N; A.Ci = Cin; A.Co = Cout; A.P = T * Ho * Wo; A.Pin = (long long)T * H * W;
     A.strided = strideHW == 2; A.T = T; A.H = H; A.W = W; A.Ho = Ho; A.Wo = Wo;
     A.units_per_sample = cdiv(A.P, WG_UNIT);
@@ -2568,6 +2636,10 @@ extern "C" int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb
                &A.it_run);
     X3D_CHECK_ARG(A.cob * A.cib <= 65535);
     dim3 grid(A.groups, A.cob * A.cib), block(256);
+    if (mx && tiled && (A.strided || getenv("X3D_WGRAD_F32") != nullptr)) {
+        x3d_set_error("pw_bwd_weight: no mixed-storage kernel for Cin=%d Cout=%d P=%d stride=%d", Cin, Cout, A.P, strideHW);
+        return X3D_EINVAL;
+    }
     if (tiled) {
         // split-bf16 MFMA (3 products, ~1e-5 on dW) by default; X3D_WGRAD_F32 selects the exact fp32-MFMA kernel
         hipStream_t s3 = (hipStream_t)stream;
@@ -2575,28 +2647,36 @@ extern "C" int x3d_pw_bwd_weight(const float* g, const float* a, const float* cb
             hipLaunchKernelGGL(pw_wgrad2_kernel, grid, block, 0, s3, A);
         } else if (A.strided) {
             if (wg3_co(Cout) == 128) {
-                if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<128, 64, true>), grid, block, 0, s3, A);
-                else hipLaunchKernelGGL((pw_wgrad3_kernel<128, 32, true>), grid, block, 0, s3, A);
+                if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<128, 64, true, false>), grid, block, 0, s3, A);
+                else hipLaunchKernelGGL((pw_wgrad3_kernel<128, 32, true, false>), grid, block, 0, s3, A);
             } else {
-                if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<64, 64, true>), grid, block, 0, s3, A);
-                else hipLaunchKernelGGL((pw_wgrad3_kernel<64, 32, true>), grid, block, 0, s3, A);
+                if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<64, 64, true, false>), grid, block, 0, s3, A);
+                else hipLaunchKernelGGL((pw_wgrad3_kernel<64, 32, true, false>), grid, block, 0, s3, A);
             }
-        } else if (wg3_co(Cout) == 128) {
-            if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<128, 64, false>), grid, block, 0, s3, A);
-            else hipLaunchKernelGGL((pw_wgrad3_kernel<128, 32, false>), grid, block, 0, s3, A);
         } else {
-            if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<64, 64, false>), grid, block, 0, s3, A);
-            else hipLaunchKernelGGL((pw_wgrad3_kernel<64, 32, false>), grid, block, 0, s3, A);
+#define WG3_GO(CO_, CI_)                                                                                       \
+    do {                                                                                                       \
+        if (mx) hipLaunchKernelGGL((pw_wgrad3_kernel<CO_, CI_, false, true>), grid, block, 0, s3, A);           \
+        else hipLaunchKernelGGL((pw_wgrad3_kernel<CO_, CI_, false, false>), grid, block, 0, s3, A);             \
+    } while (0)
+            if (wg3_co(Cout) == 128) { if (wg3_ci(Cin) == 64) WG3_GO(128, 64); else WG3_GO(128, 32); }
+            else { if (wg3_ci(Cin) == 64) WG3_GO(64, 64); else WG3_GO(64, 32); }
+#undef WG3_GO
         }
         X3D_LAUNCH_CHECK();
         return X3D_OK;
     }
     const bool vec = (A.P % 4 == 0) && !A.strided && (A.Pin % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
-#define WG_LAUNCH(CT_, IT_)                                                                         \
-    do {                                                                                            \
-        if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<CT_, IT_, true>), grid, block, 0, s, A);        \
-        else hipLaunchKernelGGL((pw_wgrad_kernel<CT_, IT_, false>), grid, block, 0, s, A);           \
+#define WG_LAUNCH(CT_, IT_)                                                                                \
+    do {                                                                                                   \
+        if (mx) {                                                                                          \
+            if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<CT_, IT_, true, true>), grid, block, 0, s, A);     \
+            else hipLaunchKernelGGL((pw_wgrad_kernel<CT_, IT_, false, true>), grid, block, 0, s, A);        \
+        } else {                                                                                           \
+            if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<CT_, IT_, true, false>), grid, block, 0, s, A);    \
+            else hipLaunchKernelGGL((pw_wgrad_kernel<CT_, IT_, false, false>), grid, block, 0, s, A);       \
+        }                                                                                                  \
     } while (0)
     if (A.ct_run <= 2 && A.it_run <= 2) WG_LAUNCH(2, 2);
     else if (A.ct_run <= 2) WG_LAUNCH(2, 4);
@@ -2614,37 +2694,56 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
     hipStream_t s = (hipStream_t)stream;
     const bool f32 = getenv("X3D_WGRAD_F32") != nullptr;
     // variant id: bit 0 = CI 64, bit 1 = CO 128, bit 2 = gathered (strided) input; -1 = not a wgrad3 shape
-    static thread_local WgBatch B[10];
-    for (int v = 0; v < 10; ++v) { B[v].njobs = 0; B[v].wg0[0] = 0; }
-    auto launch = [&](int v) -> int {
-        WgBatch& b = B[v];
+    // + 10: the same variants for jobs with bf16 tensors (mixed-storage builds of the kernels)
+    static thread_local WgBatch B[20];
+    for (int v = 0; v < 20; ++v) { B[v].njobs = 0; B[v].wg0[0] = 0; }
+    auto launch = [&](int vv) -> int {
+        WgBatch& b = B[vv];
         if (b.njobs == 0) return X3D_OK;
+        const bool mxb = vv >= 10;
+        const int v = vv % 10;
         const dim3 grid(b.wg0[b.njobs]), block(256);
         if (v >= 8) {               // wide tiles: 8 waves, dynamic LDS (two planes of dY and of the input)
             static bool attr_done = false;
             if (!attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<256, 96>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<256, 96, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 96) * W3_LD * 2);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<128, 224>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<128, 224, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 224) * W3_LD * 2);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<256, 96, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 96) * W3_LD * 2);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<128, 224, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 224) * W3_LD * 2);
                 attr_done = true;
             }
-            if (v == 8) hipLaunchKernelGGL((pw_wgrad4_batch_kernel<256, 96>), grid, dim3(512), 2 * (256 + 96) * W3_LD * 2, s, b);
-            else hipLaunchKernelGGL((pw_wgrad4_batch_kernel<128, 224>), grid, dim3(512), 2 * (128 + 224) * W3_LD * 2, s, b);
+            const size_t l1 = 2 * (256 + 96) * W3_LD * 2, l2 = 2 * (128 + 224) * W3_LD * 2;
+            if (v == 8) {
+                if (mxb) hipLaunchKernelGGL((pw_wgrad4_batch_kernel<256, 96, true>), grid, dim3(512), l1, s, b);
+                else hipLaunchKernelGGL((pw_wgrad4_batch_kernel<256, 96, false>), grid, dim3(512), l1, s, b);
+            } else {
+                if (mxb) hipLaunchKernelGGL((pw_wgrad4_batch_kernel<128, 224, true>), grid, dim3(512), l2, s, b);
+                else hipLaunchKernelGGL((pw_wgrad4_batch_kernel<128, 224, false>), grid, dim3(512), l2, s, b);
+            }
             b.njobs = 0;
             X3D_LAUNCH_CHECK();
             return X3D_OK;
         }
+#define WB_GO(CO_, CI_)                                                                                         \
+    do {                                                                                                        \
+        if (mxb) hipLaunchKernelGGL((pw_wgrad3_batch_kernel<CO_, CI_, false, true>), grid, block, 0, s, b);      \
+        else hipLaunchKernelGGL((pw_wgrad3_batch_kernel<CO_, CI_, false, false>), grid, block, 0, s, b);         \
+    } while (0)
         switch (v) {
-            case 0: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 32, false>), grid, block, 0, s, b); break;
-            case 1: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 64, false>), grid, block, 0, s, b); break;
-            case 2: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 32, false>), grid, block, 0, s, b); break;
-            case 3: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 64, false>), grid, block, 0, s, b); break;
-            case 4: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 32, true>), grid, block, 0, s, b); break;
-            case 5: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 64, true>), grid, block, 0, s, b); break;
-            case 6: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 32, true>), grid, block, 0, s, b); break;
-            default: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 64, true>), grid, block, 0, s, b); break;
+            case 0: WB_GO(64, 32); break;
+            case 1: WB_GO(64, 64); break;
+            case 2: WB_GO(128, 32); break;
+            case 3: WB_GO(128, 64); break;
+            case 4: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 32, true, false>), grid, block, 0, s, b); break;
+            case 5: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 64, true, false>), grid, block, 0, s, b); break;
+            case 6: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 32, true, false>), grid, block, 0, s, b); break;
+            default: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 64, true, false>), grid, block, 0, s, b); break;
         }
+#undef WB_GO
         b.njobs = 0;
         X3D_LAUNCH_CHECK();
         return X3D_OK;
@@ -2656,7 +2755,9 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
         X3D_CHECK_ARG(J.strideHW == 1 || J.strideHW == 2);
         WgArgs A = {};
         const int Ho = J.strideHW == 2 ? (J.H - 1) / 2 + 1 : J.H, Wo = J.strideHW == 2 ? (J.W - 1) / 2 + 1 : J.W;
-        A.g = J.g; A.a = J.a; A.cb = J.cb; A.x = J.x; A.pre = J.pre; A.pre_act = J.pre_act; A.wpartial = J.wpartial;
+        X3D_CHECK_ARG((J.mx & ~(X3D_MX_GA | X3D_MX_X)) == 0);
+        A.g = (const float*)J.g; A.a = (const float*)J.a; A.cb = J.cb; A.x = (const float*)J.x; A.pre = J.pre;
+        A.pre_act = J.pre_act; A.wpartial = J.wpartial; A.ga_bf = (J.mx & X3D_MX_GA) != 0; A.x_bf = (J.mx & X3D_MX_X) != 0;
         A.N = J.N; A.Ci = J.Cin; A.Co = J.Cout; A.P = J.T * Ho * Wo; A.Pin = (long long)J.T * J.H * J.W;
         A.strided = J.strideHW == 2; A.T = J.T; A.H = J.H; A.W = J.W; A.Ho = Ho; A.Wo = Wo;
         A.units_per_sample = cdiv(A.P, WG_UNIT);
@@ -2665,7 +2766,7 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
                    &A.ct_run, &A.it_run);
         if (!tiled || f32) {           // shapes outside the split-bf16 tiled kernel: one launch of their own
             const int rc = x3d_pw_bwd_weight(J.g, J.a, J.cb, J.x, J.pre, J.pre_act, J.wpartial, J.N, J.Cin, J.Cout, J.T,
-                                             J.H, J.W, J.strideHW, stream);
+                                             J.H, J.W, J.strideHW, J.mx, stream);
             if (rc != X3D_OK) return rc;
             continue;
         }
@@ -2676,6 +2777,13 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
             A.cob = cdiv(J.Cout, wide == 1 ? 256 : 128);
             A.cib = cdiv(J.Cin, wide == 1 ? 96 : 224);
         }
+        if (J.mx) {
+            if (A.strided) {
+                x3d_set_error("pw_bwd_weight_batch: no mixed-storage kernel for a strided conv (Cin=%d Cout=%d)", J.Cin, J.Cout);
+                return X3D_EINVAL;
+            }
+            v += 10;
+        }
         WgBatch& b = B[v];
         b.job[b.njobs] = A;
         b.wg0[b.njobs + 1] = b.wg0[b.njobs] + A.groups * A.cob * A.cib;
@@ -2684,7 +2792,7 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
             if (rc != X3D_OK) return rc;
         }
     }
-    for (int v = 0; v < 10; ++v) {
+    for (int v = 0; v < 20; ++v) {
         const int rc = launch(v);
         if (rc != X3D_OK) return rc;
     }

@@ -27,12 +27,13 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 struct P6Args {
-    const float* x;       // [N][K][P]
+    const void* x;        // [N][K][P] (fp32, or bf16 when x_bf)
     const float* cin;     // [N][K][2] or NULL
     const float* wp;      // forward pack: fp32 image, then bf16 hi / mid / lo planes
-    float* y;             // [N][M][P]
+    void* y;              // [N][M][P] (fp32, or bf16 when y_bf)
     float* partial;       // [N][M][tiles][2] or NULL
     int N, K, M, P, tiles, in_act, mblocks, mt_run;
+    int x_bf, y_bf;       // mixed-storage mode: the wide (Cmid) tensor of the conv is stored in bf16
 };
 
 constexpr int P6_BN = 32;          // voxels per item
@@ -43,8 +44,9 @@ constexpr int P6_MAXPASS = 7;      // K <= 448
 
 __device__ __forceinline__ bf16x8 cat8_(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
-template <int IN_AFF, int NPASS>
+template <int IN_AFF, int NPASS, bool MX>
 __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
+    const int x_bf = MX ? A.x_bf : 0, y_bf = MX ? A.y_bf : 0;      // fp32 build: folded away
     extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,14 +72,14 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
     const int pc = min(pt + c4, P - 4);
     const bool pvv = pt + c4 < P;
     const int colE = c4 >> 1, colO = colE + 16;
-    const float* xs = A.x + (size_t)n * K * (size_t)P;
+    const char* xs = mx_base(A.x, (size_t)n * K * (size_t)P, x_bf);
     const float* cs = IN_AFF ? A.cin + (size_t)n * K * 2 : nullptr;
     float4 rx[NPASS];
     float2 cf[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const unsigned k = (unsigned)min(row0 + P6_RP * i, K - 1);
-        rx[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xs) + (k * (unsigned)P + (unsigned)pc) * 4u);
+        rx[i] = ldo4(xs, k * (unsigned)P + (unsigned)pc, x_bf);
         if (IN_AFF) cf[i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cs) + k * 8u);
     }
     // this wave's A fragments: M tile (block mb, wave), planes behind the fp32 image of the pack
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
         for (int e = 0; e < 4; ++e) {
             const int m = mt * 16 + 4 * q + e;
             const bool mv = m < M;
-            const float v0 = pv ? acc[0][e] : 0.f, v1 = pv ? acc[1][e] : 0.f;
-            if (mv && pv) *reinterpret_cast<float2*>(A.y + ((size_t)n * M + m) * (size_t)P + pl) = make_float2(v0, v1);
+            const float v0 = stored(pv ? acc[0][e] : 0.f, y_bf), v1 = stored(pv ? acc[1][e] : 0.f, y_bf);
+            if (mv && pv) stx2(A.y, ((size_t)n * M + m) * (size_t)P + pl, y_bf, v0, v1);
             if (A.partial != nullptr) {
                 const float s1 = row16_sum(v0 + v1);
                 const float s2 = row16_sum(fmaf(v0, v0, v1 * v1));
@@ -194,19 +196,21 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
 enum { P7_PLAIN = 0, P7_ACTBWD = 1, P7_RESBWD = 2 };
 
 struct P7Args {
-    const float* g; const float* a; const float* cb;      // [N][K][P], [N][K][P], [N][K][3]
+    const void* g; const void* a; const float* cb;        // [N][K][P], [N][K][P] (bf16 when ga_bf), [N][K][3]
     const float* wp;                                       // transposed pack (M = Cin rows, K = Cout)
-    float* y;                                              // [N][M][P]
+    void* y;                                               // [N][M][P] (bf16 when y_bf)
     float* partial;                                        // [N][M][tiles][2] (ACTBWD / RESBWD)
-    const float* ex;                                       // ACTBWD: raw x; RESBWD: raw conv3 output of the producing block
+    const void* ex;                                        // ACTBWD: raw x (bf16 when ex_bf); RESBWD: raw conv3 output of the producing block
+    int ga_bf, y_bf, ex_bf;                                // mixed-storage mode
     const float* emask;                                    // RESBWD: that block's output
     const float* ecoef; int e_act;                         // ACTBWD: [N][M][2]
     const float* addend; int addend_stride;
     int N, K, M, P, tiles, T, H, W, Ho, Wo, mblocks, mt_run;
 };
 
-template <int EPI, int NPASS>
+template <int EPI, int NPASS, bool MX>
 __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const P7Args A) {
+    const int ga_bf = MX ? A.ga_bf : 0, y_bf = MX ? A.y_bf : 0, ex_bf = MX ? A.ex_bf : 0;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,17 +234,17 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
         const int pc = min(pt + c4, P - 4);
         const bool pvv = pt + c4 < P;
         const int colE = c4 >> 1, colO = colE + 16;
-        const float* gs = A.g + (size_t)n * K * (size_t)P;
-        const float* as = A.a + (size_t)n * K * (size_t)P;
+        const char* gs = mx_base(A.g, (size_t)n * K * (size_t)P, ga_bf);
+        const char* as = mx_base(A.a, (size_t)n * K * (size_t)P, ga_bf);
         const float* cs = A.cb + (size_t)n * K * 3;
         float4 rg[NPASS], ra[NPASS];
         float k0[NPASS], k1[NPASS], k2[NPASS];
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const unsigned k = (unsigned)min(row0 + P6_RP * i, K - 1);
-            const unsigned off = (k * (unsigned)P + (unsigned)pc) * 4u;
-            rg[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gs) + off);
-            ra[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(as) + off);
+            const unsigned off = k * (unsigned)P + (unsigned)pc;
+            rg[i] = ldo4(gs, off, ga_bf);
+            ra[i] = ldo4(as, off, ga_bf);
             const float* c3 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(cs) + k * 12u);
             k0[i] = c3[0]; k1[i] = c3[1]; k2[i] = c3[2];
         }
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
             esc[e] = c2.x; esh[e] = c2.y;
         }
         if (EPI != P7_PLAIN) {
-            const float2 t2 = *reinterpret_cast<const float2*>(A.ex + mrow * (size_t)P + pc2);
+            const float2 t2 = ldx2(A.ex, mrow * (size_t)P + pc2, ex_bf);
             xv[e][0] = t2.x; xv[e][1] = t2.y;
         }
         if (EPI == P7_RESBWD) {
@@ -372,11 +376,12 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
                     const float xj = pv ? xv[e][j2] : 0.f;
                     if (EPI == P7_RESBWD) v[j2] = (pv && mk[e][j2] > 0.f) ? v[j2] : 0.f;
                     else v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
+                    v[j2] = stored(v[j2], y_bf);
                     s1 += v[j2];
                     s2 = fmaf(v[j2], xj, s2);
                 }
             }
-            if (mv && pv) *reinterpret_cast<float2*>(A.y + ((size_t)n * M + m) * (size_t)P + pl) = make_float2(v[0], v[1]);
+            if (mv && pv) stx2(A.y, ((size_t)n * M + m) * (size_t)P + pl, y_bf, v[0], v[1]);
             if (EPI != P7_PLAIN && A.partial != nullptr) {
                 s1 = row16_sum(s1);
                 s2 = row16_sum(s2);
@@ -399,10 +404,10 @@ bool x3d_pw6_ok(int K, int M, int P) {
 
 int x3d_pw6_tiles(int P) { return cdiv(P, P6_BN); }
 
-int x3d_pw6_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M,
-                   int P, int in_act, hipStream_t s) {
+int x3d_pw6_launch(const void* x, const float* cin, const float* wp, void* y, float* partial, int N, int K, int M,
+                   int P, int in_act, int x_bf, int y_bf, hipStream_t s) {
     P6Args A = {};
-    A.x = x; A.cin = cin; A.wp = wp; A.y = y; A.partial = partial;
+    A.x = x; A.cin = cin; A.wp = wp; A.y = y; A.partial = partial; A.x_bf = x_bf; A.y_bf = y_bf;
     A.N = N; A.K = K; A.M = M; A.P = P; A.tiles = cdiv(P, P6_BN); A.in_act = in_act;
     const int mtiles = cdiv(M, 16);
     A.mblocks = cdiv(mtiles, 8);
@@ -413,21 +418,22 @@ int x3d_pw6_launch(const float* x, const float* cin, const float* wp, float* y, 
     const size_t lds = (size_t)3 * kp * P6_LD * sizeof(__bf16);
     const int npass = cdiv(kp, P6_RP);
     // more than 64 KB of dynamic LDS (K > 256) has to be allowed per kernel once
-#define P6_GO(AFF, NP)                                                                                              \
+#define P6_GO(AFF, NP, MX_)                                                                                         \
     do {                                                                                                            \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw6_kernel<AFF, NP>),                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw6_kernel<AFF, NP, MX_>),                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P6_RP * NP * P6_LD * 2);       \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL((pw6_kernel<AFF, NP>), grid, block, lds, s, A);                                           \
+        hipLaunchKernelGGL((pw6_kernel<AFF, NP, MX_>), grid, block, lds, s, A);                                      \
     } while (0)
-#define P6_PASS(AFF)                                                                             \
-    do {                                                                                         \
-        if (npass <= 2) P6_GO(AFF, 2); else if (npass <= 4) P6_GO(AFF, 4); else P6_GO(AFF, 7);   \
+#define P6_PASS(AFF, MX_)                                                                                      \
+    do {                                                                                                       \
+        if (npass <= 2) P6_GO(AFF, 2, MX_); else if (npass <= 4) P6_GO(AFF, 4, MX_); else P6_GO(AFF, 7, MX_);  \
     } while (0)
-    if (cin) P6_PASS(1); else P6_PASS(0);
+    if (x_bf || y_bf) { if (cin) P6_PASS(1, true); else P6_PASS(0, true); }
+    else if (cin) P6_PASS(1, false); else P6_PASS(0, false);
 #undef P6_PASS
 #undef P6_GO
     X3D_LAUNCH_CHECK();
@@ -435,18 +441,20 @@ int x3d_pw6_launch(const float* x, const float* cin, const float* wp, float* y, 
 }
 
 // ---- data gradient (pw7_kernel): K = Cout, M = Cin
-bool x3d_pw7_ok(int K, int M, int P) {
+bool x3d_pw7_ok(int K, int M, int P, int mx) {
     static const bool off = getenv("X3D_NO_PW7") != nullptr;
     // measured at the base shape: K = 216 -> M = 96 (conv1 of stage 3) is the one layer where the chunked pw5_kernel is
     // not slower (23.6 vs 24.9 us: six of the eight waves own an M tile, seven k steps of staging for each)
-    if (K > 128 && K < 256 && M <= 96) return false;
+    // (the mixed-storage mode has no chunked kernel: always here)
+    if (!mx && K > 128 && K < 256 && M <= 96) return false;
     return !off && getenv("X3D_DGRAD_F32") == nullptr && K >= 64 && K <= P6_RP * P6_MAXPASS && M >= 96 && (P % 4 == 0) && P >= 4;
 }
 
-int x3d_pw7_launch(const float* g, const float* a, const float* cb, const float* wpt, float* out, float* partial, int mode,
-                   const float* ex, const float* emask, const float* ecoef, int e_act, const float* addend,
-                   int addend_stride, int N, int K, int M, int T, int H, int W, hipStream_t s) {
+int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* wpt, void* out, float* partial, int mode,
+                   const void* ex, const float* emask, const float* ecoef, int e_act, const float* addend,
+                   int addend_stride, int N, int K, int M, int T, int H, int W, int ga_bf, int y_bf, int ex_bf, hipStream_t s) {
     P7Args A = {};
+    A.ga_bf = ga_bf; A.y_bf = y_bf; A.ex_bf = ex_bf;
     A.g = g; A.a = a; A.cb = cb; A.wp = wpt; A.y = out; A.partial = partial; A.ex = ex; A.emask = emask; A.ecoef = ecoef;
     A.e_act = e_act; A.addend = addend; A.addend_stride = addend_stride;
     A.N = N; A.K = K; A.M = M; A.P = T * H * W; A.tiles = cdiv(A.P, P6_BN); A.T = T; A.H = H; A.W = W;
@@ -459,21 +467,25 @@ int x3d_pw7_launch(const float* g, const float* a, const float* cb, const float*
     const int kp = cdiv(K, 32) * 32;
     const size_t lds = (size_t)2 * kp * P6_LD * sizeof(__bf16);
     const int npass = cdiv(kp, P6_RP);
-#define P7_GO(EPI_, NP)                                                                                             \
+#define P7_GO(EPI_, NP, MX_)                                                                                        \
     do {                                                                                                            \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP>),                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP, MX_>),                     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P6_RP * NP * P6_LD * 2);       \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL((pw7_kernel<EPI_, NP>), grid, block, lds, s, A);                                          \
+        hipLaunchKernelGGL((pw7_kernel<EPI_, NP, MX_>), grid, block, lds, s, A);                                     \
     } while (0)
-#define P7_PASS(EPI_)                                                                                  \
-    do {                                                                                               \
-        if (npass <= 2) P7_GO(EPI_, 2); else if (npass <= 4) P7_GO(EPI_, 4); else P7_GO(EPI_, 7);      \
+#define P7_PASS(EPI_, MX_)                                                                                           \
+    do {                                                                                                             \
+        if (npass <= 2) P7_GO(EPI_, 2, MX_); else if (npass <= 4) P7_GO(EPI_, 4, MX_); else P7_GO(EPI_, 7, MX_);     \
     } while (0)
-    if (mode == P7_PLAIN) P7_PASS(P7_PLAIN); else if (mode == P7_ACTBWD) P7_PASS(P7_ACTBWD); else P7_PASS(P7_RESBWD);
+    if (ga_bf || y_bf || ex_bf) {
+        if (mode == P7_PLAIN) P7_PASS(P7_PLAIN, true); else if (mode == P7_ACTBWD) P7_PASS(P7_ACTBWD, true); else P7_PASS(P7_RESBWD, true);
+    } else {
+        if (mode == P7_PLAIN) P7_PASS(P7_PLAIN, false); else if (mode == P7_ACTBWD) P7_PASS(P7_ACTBWD, false); else P7_PASS(P7_RESBWD, false);
+    }
 #undef P7_PASS
 #undef P7_GO
     X3D_LAUNCH_CHECK();

@@ -32,10 +32,10 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 enum { FE_PLAIN = 0, FE_ACTBWD = 1, FE_RESBWD = 2 };
 
 struct FbArgs {
-    const float* g; const float* a; const float* cb;     // [N][Co][P], [N][Co][P], [N][Co][3]
-    const float* x; const float* xpre; int xact;         // [N][Ci][P]; [N][Ci][2] or NULL
+    const void* g; const void* a; const float* cb;       // [N][Co][P], [N][Co][P] (bf16 in the MX = 2 build), [N][Co][3]
+    const void* x; const float* xpre; int xact;          // [N][Ci][P] (bf16 in the MX = 1 build); [N][Ci][2] or NULL
     const float* wpt;                                    // transposed pack: fp32 image, then bf16 hi / lo planes
-    float* dx;                                           // [N][Ci][P]
+    void* dx;                                            // [N][Ci][P] (bf16 in the MX = 1 build)
     float* wpartial;                                     // [groups][Co][Ci]
     float* partial;                                      // [N][Ci][tiles][2] (FE_ACTBWD / FE_RESBWD)
     const float* ex;                                     // FE_RESBWD: raw conv3 output of the producing block [N][Ci][P]
@@ -62,8 +62,11 @@ __device__ __forceinline__ bf16x8 cat8(bf16x4 lo4, bf16x4 hi4) {
 // Occupancy is the latency hiding here: a workgroup runs its chunk as fetch -> stage -> MFMA -> epilogue without a register
 // prefetch across chunks (that version needed 180-256 registers and ran at 1-2 waves per SIMD, 2x off the HBM time);
 // the global round trips of one workgroup are covered by the other 3-4 resident on the CU.
-template <int CO, int CI, int EPI, bool ADD, int NWV, int OCC>
+// MX: mixed-storage build (BASELINE config 5): 0 = every tensor fp32; 1 = x and dx are bf16 (conv3 of a bottleneck: the wide
+// Cmid tensors are its input side); 2 = g and a are bf16 (conv1: the wide tensors are its output side).
+template <int CO, int CI, int EPI, bool ADD, int NWV, int OCC, int MX>
 __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArgs A) {
+    constexpr int GA_BF = MX == 2, X_BF = MX == 1, DX_BF = MX == 1;
     constexpr int NT = 64 * NWV;                           // threads
     constexpr int RP = NT / 16;                            // rows staged per pass (16 lanes x float4 = one 64-voxel row)
     constexpr int ND = (CO + RP - 1) / RP, NX = (CI + RP - 1) / RP;   // staged float4 slots per thread (dY rows, X rows)
@@ -143,28 +146,28 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
             }
         }
         // per-sample bases are wave uniform (SGPRs); a row of one sample is < 4 GB away: 32-bit byte offsets
-        const float* gs = A.g + (size_t)n * Co * (size_t)P;
-        const float* as = A.a + (size_t)n * Co * (size_t)P;
-        const float* xs = A.x + (size_t)n * Ci * (size_t)P;
+        const char* gs = mx_base(A.g, (size_t)n * Co * (size_t)P, GA_BF);
+        const char* as = mx_base(A.a, (size_t)n * Co * (size_t)P, GA_BF);
+        const char* xs = mx_base(A.x, (size_t)n * Ci * (size_t)P, X_BF);
         const float* cbs = A.cb + (size_t)n * Co * 3;
         const float* xps = A.xpre != nullptr ? A.xpre + (size_t)n * Ci * 2 : nullptr;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const unsigned co = (unsigned)min(row0 + RP * i, Co - 1);
-            const unsigned off = (co * (unsigned)P + (unsigned)pc) * 4u;
-            rg[i] = ldg_off<float4>(gs, off);
-            ra[i] = ldg_off<float4>(as, off);
+            const unsigned off = co * (unsigned)P + (unsigned)pc;
+            rg[i] = ldo4(gs, off, GA_BF);
+            ra[i] = ldo4(as, off, GA_BF);
             k0[i] = ldg_off<float>(cbs, co * 12u); k1[i] = ldg_off<float>(cbs, co * 12u + 4u); k2[i] = ldg_off<float>(cbs, co * 12u + 8u);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const unsigned ci = (unsigned)min(row0 + RP * i, Ci - 1);
-            const unsigned xoff = (ci * (unsigned)P + (unsigned)pc) * 4u;
-            rx[i] = ldg_off<float4>(xs, xoff);
-            if (EPI == FE_RESBWD) rex[i] = ldg_off<float4>(A.ex + (size_t)n * Ci * (size_t)P, xoff);
+            const unsigned xoff = ci * (unsigned)P + (unsigned)pc;
+            rx[i] = ldo4(xs, xoff, X_BF);
+            if (EPI == FE_RESBWD) rex[i] = ldg_off<float4>(A.ex + (size_t)n * Ci * (size_t)P, xoff * 4u);
             if (ADD) {
                 if (add_dense) {
-                    radd[i] = ldg_off<float4>(A.addend + (size_t)n * Ci * (size_t)P, xoff);
+                    radd[i] = ldg_off<float4>(A.addend + (size_t)n * Ci * (size_t)P, xoff * 4u);
                 } else {
                     const unsigned addP = (unsigned)(A.T * A.Ho * A.Wo);
                     const float* ads = A.addend + (size_t)n * Ci * (size_t)addP;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
         const int vl = 32 * half + 2 * r;                     // voxel within the chunk
         const int pl = tile * F_PT + vl;
         const bool pv = pl < P;                               // P even: both voxels or none
-        float* dxs = A.dx + (size_t)n * Ci * (size_t)P;
+        char* dxs = mx_base(A.dx, (size_t)n * Ci * (size_t)P, DX_BF);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int lt = mpar + MP * j;
@@ -345,13 +348,12 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
                             v[j2] = pv ? v[j2] * act_bwd(fmaf(esc, xj, esh), A.xact) : 0.f;
                             mul = xj;
                         }
+                        v[j2] = stored(v[j2], DX_BF);
                         s1 += v[j2];
                         s2 = fmaf(v[j2], mul, s2);
                     }
                 }
-                if (mv && pv)
-                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(dxs) + ((unsigned)ml * (unsigned)P + (unsigned)pl) * 4u) =
-                        make_float2(v[0], v[1]);
+                if (mv && pv) sto2(dxs, (unsigned)ml * (unsigned)P + (unsigned)pl, DX_BF, v[0], v[1]);
                 if (EPI != FE_PLAIN) {
                     s1 = row16_sum(s1);
                     s2 = row16_sum(s2);
@@ -420,14 +422,16 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
 // Replaces the fp32-MFMA streaming kernel pw3 (3.3-3.5 TB/s at 2 waves per SIMD) for dense inputs with K, M <= 128.
 // ---------------------------------------------------------------------------------------
 struct FsArgs {
-    const float* x; const float* cin; int in_act;      // [N][K][P]; [N][K][2] or NULL
+    const void* x; const float* cin; int in_act;       // [N][K][P] (bf16 when x_bf); [N][K][2] or NULL
     const float* wp;                                    // forward pack: fp32 image, then bf16 hi / mid / lo planes
-    float* y; float* partial;                           // [N][M][P]; [N][M][tiles][2] or NULL
+    void* y; float* partial;                            // [N][M][P] (bf16 when y_bf); [N][M][tiles][2] or NULL
     int N, K, M, P, tiles;
+    int x_bf, y_bf;                                     // mixed-storage build only
 };
 
-template <int KP, int MP, int NWV>
+template <int KP, int MP, int NWV, bool MX>
 __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs A) {
+    const int x_bf = MX ? A.x_bf : 0, y_bf = MX ? A.y_bf : 0;
     constexpr int NT = 64 * NWV, RP = NT / 16;
     constexpr int NX = (KP + RP - 1) / RP;
     constexpr int KS = KP / 32;
@@ -469,12 +473,12 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
     auto fetch = [&](int c, float4 (&rx)[NX], float2 (&cf)[NX]) {
         const int n = c / cps, pt = (c - n * cps) * F_PT;
         const int pc = min(pt + c4, P - 4);
-        const float* xs = A.x + (size_t)n * K * (size_t)P;
+        const char* xs = mx_base(A.x, (size_t)n * K * (size_t)P, x_bf);
         const float* cs = A.cin != nullptr ? A.cin + (size_t)n * K * 2 : nullptr;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const unsigned k = (unsigned)min(row0 + RP * i, K - 1);
-            rx[i] = ldg_off<float4>(xs, (k * (unsigned)P + (unsigned)pc) * 4u);
+            rx[i] = ldo4(xs, k * (unsigned)P + (unsigned)pc, x_bf);
             cf[i] = make_float2(1.f, 0.f);
             if (cs != nullptr) cf[i] = ldg_off<float2>(cs, k * 8u);
         }
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
         const int n = c / cps, tile = c - n * cps;
         const int pl = tile * F_PT + 32 * half + 2 * r;
         const bool pv = pl < P;
-        float* ys = A.y + (size_t)n * M * (size_t)P;
+        char* ys = mx_base(A.y, (size_t)n * M * (size_t)P, y_bf);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int lt = mpar + MPW * j;
@@ -568,10 +572,8 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
             for (int e = 0; e < 4; ++e) {
                 const int ml = lt * 16 + 4 * q + e;
                 const bool mv = ml < M;
-                const float v0 = pv ? acc[j][0][e] : 0.f, v1 = pv ? acc[j][1][e] : 0.f;
-                if (mv && pv)
-                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(ys) + ((unsigned)ml * (unsigned)P + (unsigned)pl) * 4u) =
-                        make_float2(v0, v1);
+                const float v0 = stored(pv ? acc[j][0][e] : 0.f, y_bf), v1 = stored(pv ? acc[j][1][e] : 0.f, y_bf);
+                if (mv && pv) sto2(ys, (unsigned)ml * (unsigned)P + (unsigned)pl, y_bf, v0, v1);
                 sa[j][e][0] += row16_sum(v0 + v1);
                 sa[j][e][1] += row16_sum(fmaf(v0, v0, v1 * v1));
                 if (flush) {
@@ -628,21 +630,28 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
 static int fb_pad32(int c) { return (c + 31) / 32 * 32; }
 
 // residual mode: instantiated only where its three raw tiles fit the LDS (x3d_pw_bwd_fused_ok refuses the others)
-template <int CO, int CI, int NWV, int OCC>
+template <int CO, int CI, int NWV, int OCC, int MX>
 static void fb_launch_res(const FbArgs& A, dim3 grid, dim3 blk, hipStream_t s) {
     if constexpr (CI <= 64) {
-        if (A.addend) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_RESBWD, true, NWV, OCC>), grid, blk, 0, s, A);
-        else hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_RESBWD, false, NWV, OCC>), grid, blk, 0, s, A);
+        if (A.addend) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_RESBWD, true, NWV, OCC, MX>), grid, blk, 0, s, A);
+        else hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_RESBWD, false, NWV, OCC, MX>), grid, blk, 0, s, A);
     }
+}
+
+// MX = 1 (x and dx in bf16) is the conv3 of a bottleneck: activation backward, no addend
+template <int CO, int CI, int NWV, int OCC>
+static void fb_launch_mx1(const FbArgs& A, dim3 grid, dim3 blk, hipStream_t s) {
+    hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_ACTBWD, false, NWV, OCC, 1>), grid, blk, 0, s, A);
 }
 
 }  // namespace
 
 // shapes the fused kernel is built for: dense, P % 4 == 0, padded (Co, Ci) in the instantiated set
-extern "C" int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P, int mode, int has_addend) {
+// mx (X3D_MX_* bits): 0, X|Y (x and dx in bf16: activation-backward mode without addend only) or GA (g and a in bf16)
+extern "C" int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P, int mode, int has_addend, int mx) {
     if (P % 4 != 0 || P < 4 || mode < 0 || mode > 2) return 0;
     if (mode == 2 && Cin > 64) return 0;           // residual mode: three raw fp32 tiles of Cin rows must fit the LDS
-    (void)has_addend;
+    if (mx != 0 && mx != X3D_MX_GA && !(mx == (X3D_MX_X | X3D_MX_Y) && mode == 1 && !has_addend)) return 0;
     const int co = fb_pad32(Cout), ci = fb_pad32(Cin) == 96 ? 128 : fb_pad32(Cin);
     const int cop = co == 96 ? 128 : co;
     if (cop > 128 || ci > 128) return 0;
@@ -662,10 +671,10 @@ extern "C" int x3d_pw_bwd_fused_tiles(int P) { return (P + F_PT - 1) / F_PT; }
 
 // mode: 0 = plain (+ addend), 1 = activation backward (x raw, xpre, xact; statistics {sum out, sum out * x}),
 //       2 = residual-add + ReLU backward of the producing block (x = its output, ex = its raw conv3 output)
-extern "C" int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb, const float* wpacked_t, const float* x,
+extern "C" int x3d_pw_bwd_fused(const void* g, const void* a, const float* cb, const float* wpacked_t, const void* x,
                                 const float* xpre, int xact, int mode, const float* ex, const float* addend,
-                                int addend_stride, float* dx, float* wpartial, float* partial, int N, int Cin, int Cout,
-                                int T, int H, int W, void* stream) {
+                                int addend_stride, void* dx, float* wpartial, float* partial, int N, int Cin, int Cout,
+                                int T, int H, int W, int mx, void* stream) {
     X3D_CHECK_ARG(g && a && cb && wpacked_t && x && dx && wpartial);
     X3D_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && T > 0 && H > 0 && W > 0);
     X3D_CHECK_ARG(mode >= 0 && mode <= 2 && (addend_stride == 1 || addend_stride == 2));
@@ -673,8 +682,9 @@ extern "C" int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb,
     X3D_CHECK_ARG(mode != 1 || xpre != nullptr);
     X3D_CHECK_ARG(mode != 2 || (ex != nullptr && xpre == nullptr));
     const int P = T * H * W;
-    if (!x3d_pw_bwd_fused_ok(Cin, Cout, P, mode, addend != nullptr)) {
-        x3d_set_error("x3d_pw_bwd_fused: shape Cin=%d Cout=%d P=%d is outside the fused kernel's set", Cin, Cout, P);
+    if (!x3d_pw_bwd_fused_ok(Cin, Cout, P, mode, addend != nullptr, mx)) {
+        x3d_set_error("x3d_pw_bwd_fused: shape Cin=%d Cout=%d P=%d mode=%d mx=%d is outside the fused kernel's set", Cin, Cout, P,
+                      mode, mx);
         return X3D_EINVAL;
     }
     FbArgs A = {};
@@ -687,17 +697,23 @@ extern "C" int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb,
     int co = fb_pad32(Cout), ci = fb_pad32(Cin);
     if (co == 96) co = 128;
     if (ci == 96) ci = 128;
-#define FB_LAUNCH2(CO_, CI_, EPI_, NWV_, OCC_)                                                                          \
+#define FB_LAUNCH2(CO_, CI_, EPI_, NWV_, OCC_, MX_)                                                                     \
     do {                                                                                                                    \
-        if (addend) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, EPI_, true, NWV_, OCC_>), grid, blk, 0, s, A);          \
-        else hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, EPI_, false, NWV_, OCC_>), grid, blk, 0, s, A);                \
+        if (addend) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, EPI_, true, NWV_, OCC_, MX_>), grid, blk, 0, s, A);     \
+        else hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, EPI_, false, NWV_, OCC_, MX_>), grid, blk, 0, s, A);           \
+    } while (0)
+#define FB_LAUNCH3(CO_, CI_, NWV_, OCC_, MX_)                                                                            \
+    do {                                                                                                                    \
+        if (mode == 0) FB_LAUNCH2(CO_, CI_, FE_PLAIN, NWV_, OCC_, MX_);                                                      \
+        else if (mode == 1) FB_LAUNCH2(CO_, CI_, FE_ACTBWD, NWV_, OCC_, MX_);                                                \
+        else fb_launch_res<CO_, CI_, NWV_, OCC_, MX_>(A, grid, blk, s);                                                      \
     } while (0)
 #define FB_LAUNCH(CO_, CI_, NWV_, OCC_)                                                                                  \
     do {                                                                                                                    \
         const dim3 blk(64 * NWV_);                                                                                          \
-        if (mode == 0) FB_LAUNCH2(CO_, CI_, FE_PLAIN, NWV_, OCC_);                                                           \
-        else if (mode == 1) FB_LAUNCH2(CO_, CI_, FE_ACTBWD, NWV_, OCC_);                                                     \
-        else fb_launch_res<CO_, CI_, NWV_, OCC_>(A, grid, blk, s);                                                           \
+        if (mx == 0) FB_LAUNCH3(CO_, CI_, NWV_, OCC_, 0);                                                                    \
+        else if (mx == X3D_MX_GA) FB_LAUNCH3(CO_, CI_, NWV_, OCC_, 2);                                                       \
+        else fb_launch_mx1<CO_, CI_, NWV_, OCC_>(A, grid, blk, s);                                                           \
     } while (0)
     // narrow shapes (stage 1): 4 waves, 4 workgroups per CU; wide ones (stage 2): 8 waves, 2 workgroups per CU
     if (co == 32 && ci == 64) FB_LAUNCH(32, 64, 8, 4);
@@ -707,6 +723,7 @@ extern "C" int x3d_pw_bwd_fused(const float* g, const float* a, const float* cb,
     else if (co == 128 && ci == 32) FB_LAUNCH(128, 32, 16, 4);
     else FB_LAUNCH(128, 64, 16, 4);
 #undef FB_LAUNCH
+#undef FB_LAUNCH3
 #undef FB_LAUNCH2
     X3D_LAUNCH_CHECK();
     return X3D_OK;
@@ -729,17 +746,22 @@ int x3d_pwfs_tiles(int N, int P) {
 }
 
 extern "C" int x3d_pw_bwd_fused_groups(int N, int P);
-int x3d_pwfs_launch(const float* x, const float* cin, const float* wp, float* y, float* partial, int N, int K, int M, int P,
-                    int in_act, hipStream_t s) {
+int x3d_pwfs_launch(const void* x, const float* cin, const float* wp, void* y, float* partial, int N, int K, int M, int P,
+                    int in_act, int x_bf, int y_bf, hipStream_t s) {
     FsArgs A = {};
+    A.x_bf = x_bf; A.y_bf = y_bf;
     A.x = x; A.cin = cin; A.in_act = in_act; A.wp = wp; A.y = y; A.partial = partial;
     A.N = N; A.K = K; A.M = M; A.P = P; A.tiles = x3d_pwfs_tiles(N, P);
     const dim3 grid(x3d_pw_bwd_fused_groups(N, P)), blk(512);
     const int kp = fb_pad32(K) == 96 ? 128 : fb_pad32(K), mp = fb_pad32(M) == 96 ? 128 : fb_pad32(M);
-#define FS_GO(KP_, MP_) hipLaunchKernelGGL((pw_fwd_stream_kernel<KP_, MP_, 8>), grid, blk, 0, s, A)
+    // x3d_pwfs_ok: K <= 64 and M >= K
+#define FS_GO(KP_, MP_)                                                                                      \
+    do {                                                                                                     \
+        if (x_bf || y_bf) hipLaunchKernelGGL((pw_fwd_stream_kernel<KP_, MP_, 8, true>), grid, blk, 0, s, A);  \
+        else hipLaunchKernelGGL((pw_fwd_stream_kernel<KP_, MP_, 8, false>), grid, blk, 0, s, A);              \
+    } while (0)
     if (kp == 32) { if (mp == 32) FS_GO(32, 32); else if (mp == 64) FS_GO(32, 64); else FS_GO(32, 128); }
-    else if (kp == 64) { if (mp == 32) FS_GO(64, 32); else if (mp == 64) FS_GO(64, 64); else FS_GO(64, 128); }
-    else { if (mp == 32) FS_GO(128, 32); else if (mp == 64) FS_GO(128, 64); else FS_GO(128, 128); }
+    else { if (mp <= 64) FS_GO(64, 64); else FS_GO(64, 128); }
 #undef FS_GO
     X3D_LAUNCH_CHECK();
     return X3D_OK;

@@ -267,7 +267,7 @@ def get_blocks(version):
 class ResNet(nn.Module):
 
     def __init__(self, block, layers, block_inplanes, n_input_channels=3, shortcut_type='B', widen_factor=1.0,
-                 dropout=0.5, n_classes=400, base_bn_splits=8, task='class'):
+                 dropout=0.5, n_classes=400, base_bn_splits=8, task='class', act_dtype=torch.float32):
         super().__init__()
         if shortcut_type != 'B':
             raise NotImplementedError("only shortcut_type 'B' (conv + BN downsample) is built; "
@@ -277,6 +277,9 @@ class ResNet(nn.Module):
         block_inplanes = [(int(a * widen_factor), int(b * widen_factor)) for a, b in block_inplanes]
         self.base_bn_splits = base_bn_splits
         self.task = task
+        # storage type of the wide tensors inside the bottlenecks (x3dhip.engine.wide_dtype): torch.bfloat16 selects the
+        # mixed-storage mode (bf16 storage / fp32 accumulate); not in the reference, whose tensors are all fp32
+        self.act_dtype = act_dtype
         self.in_planes = block_inplanes[0][1]
         self.index = 0
         self._pending_tracked = 0

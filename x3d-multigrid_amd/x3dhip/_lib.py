@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx3dhip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 
@@ -23,38 +23,38 @@ _Z = ctypes.c_size_t
 # tests/test_abi.py checks the two against each other.
 SIGNATURES = {
     "x3d_abi_version": (_I, []),
-    "x3d_dw333_fwd_stats": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P, _P]),
+    "x3d_dw333_fwd_stats": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P, _I, _P]),
     "x3d_bn_stats_add_relu_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "x3d_clip_job_bytes": (_Z, []),
     "x3d_clip_preprocess": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "x3d_last_error": (ctypes.c_char_p, []),
     "x3d_pw_tiles": (_I, [_I, _I, _I, _I, _I]),
     "x3d_pw_fwd_tiles": (_I, [_I, _I, _I, _I, _I, _I]),
-    "x3d_pw_bwd_tiles": (_I, [_I, _I, _I, _I, _I]),
+    "x3d_pw_bwd_tiles": (_I, [_I, _I, _I, _I, _I, _I]),
     "x3d_pw_wants_packed": (_I, [_I, _I]),
     "x3d_pw_pack_floats": (_Z, [_I, _I, _I]),
     "x3d_pw_pack_items": (_Z, [_I, _I, _I]),
     "x3d_pw_pack": (_I, [_P, _P, _I, _I, _I, _P]),
     "x3d_pw_pack_job_bytes": (_Z, []),
     "x3d_pw_pack_batch": (_I, [_P, _P, _I, _P]),
-    "x3d_pw_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
-    "x3d_pw_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P]),
-    "x3d_pw_bwd_data_res": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
-    "x3d_pw_bwd_fused_ok": (_I, [_I, _I, _I, _I, _I]),
+    "x3d_pw_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "x3d_pw_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "x3d_pw_bwd_data_res": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
+    "x3d_pw_bwd_fused_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "x3d_pw_bwd_fused_groups": (_I, [_I, _I]),
     "x3d_pw_bwd_fused_tiles": (_I, [_I]),
-    "x3d_pw_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "x3d_pw_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_pw_wgrad_groups": (_I, [_I, _I, _I, _I, _I]),
-    "x3d_pw_bwd_weight": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "x3d_pw_bwd_weight": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_reduce_partials": (_I, [_P, _P, _I, _I, _P]),
     "x3d_wgrad_job_bytes": (ctypes.c_size_t, []),
     "x3d_pw_bwd_weight_batch": (_I, [_P, _I, _P]),
     "x3d_reduce_partials_batch": (_I, [_P, _P, _P, _P, _I, _P]),
     "x3d_dw_tiles": (_I, [_I, _I, _I, _I]),
-    "x3d_dw333_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "x3d_dw333_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "x3d_dw_bwd_tiles": (_I, [_I, _I, _I, _I, _I]),
-    "x3d_dw333_bwd_stats": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "x3d_dw333_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "x3d_dw333_bwd_stats": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "x3d_dw333_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_stem133_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_stem_wgrad_groups": (_I, [_I, _I]),
     "x3d_stem133_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

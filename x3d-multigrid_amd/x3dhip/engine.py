@@ -142,7 +142,7 @@ def _fused_bwd(grads, g, x, mode=0, has_addend=False):
         return False
     if tuple(x.shape[2:]) != tuple(g.shape[2:]):
         return False
-    return ops.pw_bwd_fused_ok(x.shape[1], g.shape[1], g[0, 0].numel(), mode, has_addend)
+    return ops.pw_bwd_fused_ok(x.shape[1], g.shape[1], g[0, 0].numel(), mode, has_addend, ops.pw_bwd_fused_mx(g, x))
 
 
 def _bn_train(partial, bn, S, count, want_nsum=False):
@@ -179,7 +179,7 @@ def trunk_forward(model, x, training, ctx=None):
     cur_raw, cur_coef = a_t, c0          # lazy: consumers apply relu(c0 * a_t)
     for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
         for blk in layer:
-            cur_raw, cur_coef = _block_forward(blk, cur_raw, cur_coef, S, training, ctx, packs)
+            cur_raw, cur_coef = _block_forward(blk, cur_raw, cur_coef, S, training, ctx, packs, wide_dtype(model))
 
     # ---- conv5 / bn5 / relu / global average pool
     w5 = _w2d(model.conv5.weight)
@@ -195,12 +195,25 @@ def trunk_forward(model, x, training, ctx=None):
     return pooled
 
 
-def _block_forward(blk, x_raw, x_coef, S, training, ctx, packs):
+def wide_dtype(model):
+    """Storage type of the wide (planes = 2.25 x width, x3d.py:112-116) tensors inside every bottleneck: conv1's and
+    conv2's raw outputs and their gradients.  torch.float32 (default) or torch.bfloat16 = the mixed-storage mode of
+    BASELINE config 5 (`model.act_dtype`, set by generate_model(..., act_dtype=...) or assigned later; every other
+    tensor, all arithmetic and all statistics stay fp32)."""
+    dt = getattr(model, "act_dtype", torch.float32)
+    if dt not in (torch.float32, torch.bfloat16):
+        raise ValueError("act_dtype must be torch.float32 or torch.bfloat16")
+    return dt
+
+
+def _block_forward(blk, x_raw, x_coef, S, training, ctx, packs, wide=torch.float32):
     N = x_raw.shape[0]
     pre_act = ACT_RELU if x_coef is not None else ACT_NONE
     stride = blk.stride
     w1, w3 = _w2d(blk.conv1.weight), _w2d(blk.conv3.weight)
-    a1, p1 = ops.pw_fwd(x_raw, w1, pre=x_coef, pre_act=pre_act, want_stats=training, wp=packs.get(blk.conv1.weight))
+    # conv1's output is the first wide tensor; conv2 keeps its input's storage type, conv3 returns to fp32
+    a1, p1 = ops.pw_fwd(x_raw, w1, pre=x_coef, pre_act=pre_act, want_stats=training, wp=packs.get(blk.conv1.weight),
+                        out_dtype=wide)
     P1 = a1[0, 0].numel()
     if training and not _NO_DW_STATS:
         # bn1's finalize runs inside the depthwise kernel's prologue (one launch less per block)
@@ -467,7 +480,7 @@ def _block_backward(rec, dout, grads, below=None):
     else:
         _wgrad(grads, blk.conv3.weight, g3, a3, cb3, a2, pre=rec["c2e"], pre_act=ACT_SWISH)
         ds, ps = ops.pw_bwd_data(g3, a3, cb3, _w2d(blk.conv3.weight), x=a2, pre=rec["c2e"], pre_act=ACT_SWISH,
-                                 wpt=rec["w3t"])
+                                 wpt=rec["w3t"], out_dtype=a2.dtype)
     if blk.has_se:
         se = rec["se"]
         outs = None

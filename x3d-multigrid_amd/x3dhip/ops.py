@@ -22,12 +22,39 @@ def _need_cuda(*ts):
                 raise _lib.X3DHipError("x3dhip ops need contiguous float32 tensors")
 
 
+# Mixed-storage mode (include/x3dhip.h X3D_MX_*): the wide tensors inside a bottleneck may be torch.bfloat16; the flags
+# below are derived from the tensors' dtypes, so a call is fp32 exactly when all of its tensors are.
+MX_X, MX_Y, MX_GA = 1, 2, 4
+
+
+def _need_act(*ts):
+    """Activation tensors: contiguous CUDA(HIP) float32 or bfloat16."""
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise _lib.X3DHipError("x3dhip ops need CUDA(HIP) tensors; got a CPU tensor "
+                                       "(the product path has no CPU fallback)")
+            if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous():
+                raise _lib.X3DHipError("x3dhip ops need contiguous float32 (or, mixed-storage mode, bfloat16) activations")
+
+
+def _bf(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def _same_dtype(name, *ts):
+    ts = [t for t in ts if t is not None]
+    if any(t.dtype != ts[0].dtype for t in ts):
+        raise _lib.X3DHipError("%s: tensors that share a storage flag must have one dtype (got %s)"
+                               % (name, [str(t.dtype) for t in ts]))
+
+
 def out_hw(h, stride):
     return (h - 1) // 2 + 1 if stride == 2 else h
 
 
-def _f(shape, like):
-    return torch.empty(shape, dtype=torch.float32, device=like.device)
+def _f(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
 
 
 _scratch = {}
@@ -70,32 +97,39 @@ def pw_pack(w, transposed=False):
     return wp
 
 
-def pw_fwd(x, w, stride=1, pre=None, pre_act=ACT_NONE, want_stats=True, out=None, partial=None, wp=None):
-    _need_cuda(x, w, pre)
+def pw_fwd(x, w, stride=1, pre=None, pre_act=ACT_NONE, want_stats=True, out=None, partial=None, wp=None,
+           out_dtype=torch.float32):
+    """out_dtype=torch.bfloat16 (or a bfloat16 x): mixed-storage mode, see X3D_MX_* in include/x3dhip.h."""
+    _need_cuda(w, pre)
+    _need_act(x, out)
     L = _lib.lib()
     N, Cin, T, H, W = x.shape
     Cout = w.shape[0]
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
-    y = out if out is not None else _f((N, Cout, T, Ho, Wo), x)
+    y = out if out is not None else _f((N, Cout, T, Ho, Wo), x, out_dtype)
+    mx = (MX_X if _bf(x) else 0) | (MX_Y if _bf(y) else 0)
     if want_stats and partial is None:
         partial = _f((N, Cout, L.x3d_pw_fwd_tiles(N, Cin, Cout, T * Ho * Wo, 1 if stride == 1 else 0,
                                                   1 if wp is not None else 0), 2), x)
     check(L.x3d_pw_fwd(ptr(x), ptr(w), ptr(wp), ptr(y), N, Cin, Cout, T, H, W, stride, ptr(pre), pre_act,
-                       ptr(partial) if want_stats else None, _lib.stream()))
+                       ptr(partial) if want_stats else None, mx, _lib.stream()))
     return y, (partial if want_stats else None)
 
 
 def pw_bwd_data(g, a, cb, w, x=None, pre=None, pre_act=ACT_NONE, addend=None, addend_stride=1,
-                out=None, partial=None, wpt=None):
-    _need_cuda(g, a, cb, w, x, pre, addend)
+                out=None, partial=None, wpt=None, out_dtype=torch.float32):
+    _need_cuda(cb, w, pre, addend)
+    _need_act(g, a, x, out)
+    _same_dtype("pw_bwd_data", g, a)
     L = _lib.lib()
     N, Cout, T, H, W = g.shape
     Cin = w.shape[1]
-    o = out if out is not None else _f((N, Cin, T, H, W), g)
+    o = out if out is not None else _f((N, Cin, T, H, W), g, out_dtype)
+    mx = (MX_GA if _bf(g) else 0) | (MX_X if _bf(x) else 0) | (MX_Y if _bf(o) else 0)
     if pre is not None and partial is None:
-        partial = _f((N, Cin, L.x3d_pw_bwd_tiles(N, Cin, Cout, T * H * W, 1 if wpt is not None else 0), 2), g)
+        partial = _f((N, Cin, L.x3d_pw_bwd_tiles(N, Cin, Cout, T * H * W, 1 if wpt is not None else 0, mx), 2), g)
     check(L.x3d_pw_bwd_data(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(wpt), ptr(o), N, Cin, Cout, T, H, W, ptr(x), ptr(pre),
-                            pre_act, ptr(addend), addend_stride, ptr(partial) if pre is not None else None,
+                            pre_act, ptr(addend), addend_stride, ptr(partial) if pre is not None else None, mx,
                             _lib.stream()))
     return o, (partial if pre is not None else None)
 
@@ -103,16 +137,19 @@ def pw_bwd_data(g, a, cb, w, x=None, pre=None, pre_act=ACT_NONE, addend=None, ad
 def pw_bwd_data_res(g, a, cb, w, res_out, res_raw, addend=None, addend_stride=1, wpt=None):
     """pw_bwd_data with the residual-add + ReLU backward of the block that produced this conv's input in its epilogue:
     returns (g3, partial) of that block -- what bn_add_relu_bwd(dout, out, a3) returns for a block without downsample."""
-    _need_cuda(g, a, cb, w, res_out, res_raw, addend)
+    _need_cuda(cb, w, res_out, res_raw, addend)
+    _need_act(g, a)
+    _same_dtype("pw_bwd_data_res", g, a)
     L = _lib.lib()
     N, Cout, T, H, W = g.shape
     Cin = w.shape[1]
     if tuple(res_out.shape) != (N, Cin, T, H, W) or tuple(res_raw.shape) != (N, Cin, T, H, W):
         raise ValueError("pw_bwd_data_res: res_out / res_raw must be [N, Cin, T, H, W]")
     o = _f((N, Cin, T, H, W), g)
-    partial = _f((N, Cin, L.x3d_pw_bwd_tiles(N, Cin, Cout, T * H * W, 1 if wpt is not None else 0), 2), g)
+    mx = MX_GA if _bf(g) else 0
+    partial = _f((N, Cin, L.x3d_pw_bwd_tiles(N, Cin, Cout, T * H * W, 1 if wpt is not None else 0, mx), 2), g)
     check(L.x3d_pw_bwd_data_res(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(wpt), ptr(o), N, Cin, Cout, T, H, W, ptr(res_out),
-                                ptr(res_raw), ptr(addend), addend_stride, ptr(partial), _lib.stream()))
+                                ptr(res_raw), ptr(addend), addend_stride, ptr(partial), mx, _lib.stream()))
     return o, partial
 
 
@@ -147,7 +184,7 @@ class _WgradJob(ctypes.Structure):          # X3DWgradJob (include/x3dhip.h)
     _fields_ = [("g", ctypes.c_void_p), ("a", ctypes.c_void_p), ("cb", ctypes.c_void_p), ("x", ctypes.c_void_p),
                 ("pre", ctypes.c_void_p), ("wpartial", ctypes.c_void_p), ("pre_act", ctypes.c_int), ("N", ctypes.c_int),
                 ("Cin", ctypes.c_int), ("Cout", ctypes.c_int), ("T", ctypes.c_int), ("H", ctypes.c_int),
-                ("W", ctypes.c_int), ("strideHW", ctypes.c_int)]
+                ("W", ctypes.c_int), ("strideHW", ctypes.c_int), ("mx", ctypes.c_int)]
 
 
 class DeferredGrads:
@@ -170,7 +207,10 @@ class DeferredGrads:
 
 
 def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, out=None, wpartial=None, defer=None):
-    _need_cuda(g, a, cb, x, pre)
+    _need_cuda(cb, pre)
+    _need_act(g, a, x)
+    _same_dtype("pw_bwd_weight", g, a)
+    mx = (MX_GA if _bf(g) else 0) | (MX_X if _bf(x) else 0)
     L = _lib.lib()
     N, Cin, T, H, W = x.shape
     Cout = g.shape[1]
@@ -179,23 +219,25 @@ def pw_bwd_weight(g, a, cb, x, w_shape, stride=1, pre=None, pre_act=ACT_NONE, ou
     if wpartial is None:
         wpartial = _f((groups, Cout, Cin), g)
     if defer is not None:                 # kernel and group sum postponed to the batched launches (DeferredGrads.flush)
-        for t in (g, a, cb, x) + ((pre,) if pre is not None else ()):
-            if not t.is_contiguous() or t.dtype != torch.float32:
-                raise ValueError("pw_bwd_weight: contiguous float32 tensors required")
         o = out if out is not None else _f((Cout * Cin,), g)
         defer.wjobs.append(_WgradJob(ptr(g), ptr(a), ptr(cb), ptr(x), ptr(pre), ptr(wpartial), pre_act, N, Cin, Cout, T,
-                                     H, W, stride))
+                                     H, W, stride, mx))
         defer.keep.append((g, a, cb, x, pre, wpartial))
         defer.reduces.append((wpartial.view(groups, -1), o))
         return o.view(w_shape)
     check(L.x3d_pw_bwd_weight(ptr(g), ptr(a), ptr(cb), ptr(x), ptr(pre), pre_act, ptr(wpartial), N, Cin, Cout, T,
-                              H, W, stride, _lib.stream()))
+                              H, W, stride, mx, _lib.stream()))
     dw = reduce_partials(wpartial.view(groups, -1), Cout * Cin, out=out)
     return dw.view(w_shape)
 
 
-def pw_bwd_fused_ok(Cin, Cout, P, mode=0, has_addend=False):
-    return bool(_lib.lib().x3d_pw_bwd_fused_ok(Cin, Cout, P, mode, 1 if has_addend else 0))
+def pw_bwd_fused_ok(Cin, Cout, P, mode=0, has_addend=False, mx=0):
+    return bool(_lib.lib().x3d_pw_bwd_fused_ok(Cin, Cout, P, mode, 1 if has_addend else 0, mx))
+
+
+def pw_bwd_fused_mx(g, x):
+    """Storage flags of a fused backward call with upstream gradient g and forward input x (dx takes x's dtype)."""
+    return (MX_GA if _bf(g) else 0) | ((MX_X | MX_Y) if _bf(x) else 0)
 
 
 def pw_bwd_fused(g, a, cb, w_shape, wpt, x, xpre=None, xact=ACT_NONE, mode=0, ex=None, addend=None, addend_stride=1,
@@ -204,7 +246,9 @@ def pw_bwd_fused(g, a, cb, w_shape, wpt, x, xpre=None, xact=ACT_NONE, mode=0, ex
     backward (x raw, xpre), 2 residual-add + ReLU backward of the producing block (x = its output, ex = its raw conv3
     output).  Returns (dx, partial or None, dW); the group sum of the dW partials goes to `defer` (DeferredGrads) when
     given, else it runs here."""
-    _need_cuda(g, a, cb, wpt, x, xpre, ex, addend)
+    _need_cuda(cb, wpt, xpre, ex, addend)
+    _need_act(g, a, x)
+    _same_dtype("pw_bwd_fused", g, a)
     L = _lib.lib()
     N, Cout, T, H, W = g.shape
     Cin = x.shape[1]
@@ -212,11 +256,13 @@ def pw_bwd_fused(g, a, cb, w_shape, wpt, x, xpre=None, xact=ACT_NONE, mode=0, ex
     if tuple(x.shape) != (N, Cin, T, H, W):
         raise ValueError("pw_bwd_fused: x must be [N, Cin, T, H, W] of the gradient's geometry (dense convolution)")
     groups = L.x3d_pw_bwd_fused_groups(N, P)
-    dx = _f((N, Cin, T, H, W), g)
+    mx = pw_bwd_fused_mx(g, x)
+    dx = _f((N, Cin, T, H, W), g, x.dtype)          # the gradient of a bf16 tensor is stored as bf16
     wpartial = _f((groups, Cout * Cin), g)
     partial = _f((N, Cin, L.x3d_pw_bwd_fused_tiles(P), 2), g) if mode != 0 else None
     check(L.x3d_pw_bwd_fused(ptr(g), ptr(a), ptr(cb), ptr(wpt), ptr(x), ptr(xpre), xact, mode, ptr(ex), ptr(addend),
-                             addend_stride, ptr(dx), ptr(wpartial), ptr(partial), N, Cin, Cout, T, H, W, _lib.stream()))
+                             addend_stride, ptr(dx), ptr(wpartial), ptr(partial), N, Cin, Cout, T, H, W, mx,
+                             _lib.stream()))
     o = dw_out if dw_out is not None else _f((Cout * Cin,), g)
     if defer is not None:
         defer.reduces.append((wpartial, o))
@@ -228,32 +274,35 @@ def pw_bwd_fused(g, a, cb, w_shape, wpt, x, xpre=None, xact=ACT_NONE, mode=0, ex
 
 # ----------------------------------------------------------------------------- channelwise
 def dw333_fwd(x, w, stride=1, pre=None, pre_act=ACT_RELU, want_stats=True, out=None, partial=None):
-    _need_cuda(x, w, pre)
+    _need_cuda(w, pre)
+    _need_act(x, out)
+    _same_dtype("dw333_fwd", x, out)
     L = _lib.lib()
     N, C, T, H, W = x.shape
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
-    y = out if out is not None else _f((N, C, T, Ho, Wo), x)
+    y = out if out is not None else _f((N, C, T, Ho, Wo), x, x.dtype)
     if want_stats and partial is None:
         partial = _f((N, C, L.x3d_dw_tiles(N, C, Ho, Wo), 2), x)
     check(L.x3d_dw333_fwd(ptr(x), ptr(w), ptr(y), N, C, T, H, W, stride, ptr(pre), pre_act,
-                          ptr(partial) if want_stats else None, _lib.stream()))
+                          ptr(partial) if want_stats else None, (MX_X | MX_Y) if _bf(x) else 0, _lib.stream()))
     return y, (partial if want_stats else None)
 
 
 def dw333_fwd_stats(x, w, spartial, S, count, gamma, beta, running_mean, running_var, stride=1, pre_act=ACT_RELU,
                     momentum=0.1, eps=1e-5):
     """dw333_fwd in training with the producer BN's finalize folded in.  Returns (y, partial, coef[N,C,2], save[2,S,C])."""
-    _need_cuda(x, w, spartial)
+    _need_cuda(w, spartial)
+    _need_act(x)
     L = _lib.lib()
     N, C, T, H, W = x.shape
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
-    y = _f((N, C, T, Ho, Wo), x)
+    y = _f((N, C, T, Ho, Wo), x, x.dtype)
     partial = _f((N, C, L.x3d_dw_tiles(N, C, Ho, Wo), 2), x)
     coef = _f((N, C, 2), x)
     save = _f((2, S, C), x)
     check(L.x3d_dw333_fwd_stats(ptr(x), ptr(w), ptr(y), N, C, T, H, W, stride, ptr(spartial), spartial.shape[2], S, count,
                                 ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), momentum, eps, ptr(save),
-                                ptr(coef), pre_act, ptr(partial), _lib.stream()))
+                                ptr(coef), pre_act, ptr(partial), (MX_X | MX_Y) if _bf(x) else 0, _lib.stream()))
     return y, partial, coef, save
 
 
@@ -263,11 +312,14 @@ def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wp
     partials to dw333_bwd_reduce (postponed by the engine: nothing in the backward chain reads dW).
     bn = (spartial [N,C,stiles,2], count, gamma, save [2,1,C], dgamma [C], dbeta [C]) with cb = None: the producer BN's
     backward finalize (single split) runs in the kernel's prologue; dgamma / dbeta are written."""
-    _need_cuda(g, a, cb, w, x, pre)
+    _need_cuda(cb, w, pre)
+    _need_act(g, a, x, out)
+    _same_dtype("dw333_bwd", g, a, x, out)
+    mx = (MX_GA | MX_X | MX_Y) if _bf(x) else 0
     L = _lib.lib()
     N, C, T, H, W = x.shape
     tiles = L.x3d_dw_bwd_tiles(N, C, H, W, stride)
-    o = out if out is not None else _f(x.shape, x)
+    o = out if out is not None else _f(x.shape, x, x.dtype)
     if wpartial is None:
         wpartial = _f((N, tiles, C, 27), x)
     if partial is None:
@@ -279,10 +331,10 @@ def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wp
         _need_cuda(sp, gamma, save, dgamma, dbeta)
         check(L.x3d_dw333_bwd_stats(ptr(g), ptr(a), ptr(sp), sp.shape[2], count, ptr(gamma), ptr(save), ptr(dgamma),
                                     ptr(dbeta), ptr(w), ptr(x), ptr(pre), pre_act, ptr(o), ptr(wpartial), ptr(partial),
-                                    N, C, T, H, W, stride, _lib.stream()))
+                                    N, C, T, H, W, stride, mx, _lib.stream()))
     else:
         check(L.x3d_dw333_bwd(ptr(g), ptr(a), ptr(cb), ptr(w), ptr(x), ptr(pre), pre_act, ptr(o), ptr(wpartial),
-                              ptr(partial), N, C, T, H, W, stride, _lib.stream()))
+                              ptr(partial), N, C, T, H, W, stride, mx, _lib.stream()))
     if not reduce:
         return o, wpartial, partial
     return o, dw333_bwd_reduce(wpartial, w.shape, dw_out), partial
