@@ -37,8 +37,10 @@ _ARCH = {  # (cm, co, blocks) per stage: x3d.py:352-363 ("L": XL depth at M widt
 }
 
 
-def algorithmic_elems_M(T, H, version="M"):
-    """E(T,H,W) of SURVEY.md 8(d) (elements per clip): sum over every Conv3d of in+out elements + 3 x block outputs."""
+def algorithmic_elems_M(T, H, version="M", split=False):
+    """E(T,H,W) of SURVEY.md 8(d) (elements per clip): sum over every Conv3d of in+out elements + 3 x block outputs.
+    split=True: (E, E_wide) with E_wide the part of E that touches the wide (planes-channel) tensors inside the
+    bottlenecks -- the ones the mixed-storage mode keeps in bf16."""
     def o(h):
         return (h - 1) // 2 + 1
     h = [H]
@@ -48,6 +50,7 @@ def algorithmic_elems_M(T, H, version="M"):
     arch = _ARCH[version]
     c0 = arch[0][1]
     E = 3 * S[0] + c0 * S[1] + 2 * c0 * S[1]       # conv1_s in+out, conv1_t in+out
+    Ew = 0
     cin = c0
     for k, (cm, co, n) in enumerate(arch):
         sp, sk = S[k + 1], S[k + 2]
@@ -55,9 +58,10 @@ def algorithmic_elems_M(T, H, version="M"):
         E += (cin + cm) * sp + cm * (sp + sk) + (cm + co) * sk + cin * sp + co * sk
         E += (n - 1) * ((co + cm) * sk + 2 * cm * sk + (cm + co) * sk)
         E += 3 * n * co * sk
+        Ew += cm * sp + cm * (sp + sk) + cm * sk + (n - 1) * 4 * cm * sk
         cin = co
     E += (arch[3][1] + arch[3][0]) * S[5] + arch[3][0] + 2048
-    return E
+    return (E, Ew) if split else E
 
 
 class KernelTimer:
@@ -139,32 +143,32 @@ class KernelTimer:
 def _alg_bytes(name, a, k, r):
     """Algorithmic bytes of one launch: 4 B x (input elements + output elements) of the conv /
     elementwise pass it implements (what the pass must move at minimum)."""
-    n = lambda t: t.numel()
+    n = lambda t: t.numel() * t.element_size()          # bytes as stored (4 per element; 2 for the bf16 wide tensors)
     try:
         if name in ("pw_fwd", "dw333_fwd", "dw333_fwd_stats", "dw5t_fwd", "stem133_fwd"):
             x, y = a[0], (r[0] if isinstance(r, tuple) else r)
             stride = k.get("stride", 1)
             xin = n(x) // (stride * stride) if name == "pw_fwd" else n(x)
-            return 4 * (xin + n(y))
+            return xin + n(y)
         if name in ("pw_bwd_data", "pw_bwd_data_res"):
-            return 4 * (n(a[0]) + n(r[0]))
+            return n(a[0]) + n(r[0])
         if name == "pw_bwd_fused":                      # data-gradient pass + weight-gradient pass of SURVEY 8(d), one launch
-            return 4 * (n(a[0]) + n(r[0])) + 4 * (n(a[0]) + n(a[5]))
+            return (n(a[0]) + n(r[0])) + (n(a[0]) + n(a[5]))
         if name == "pw_bwd_weight":
             stride = k.get("stride", 1)
-            return 4 * (n(a[0]) + n(a[3]) // (stride * stride))
+            return n(a[0]) + n(a[3]) // (stride * stride)
         if name == "dw333_bwd":
-            return 4 * 2 * (n(a[0]) + n(a[4]))          # fused data + weight pass
+            return 2 * (n(a[0]) + n(a[4]))              # fused data + weight pass
         if name == "dw5t_bwd":
-            return 4 * 2 * (n(a[0]) + n(a[4]))
+            return 2 * (n(a[0]) + n(a[4]))
         if name == "stem133_bwd_weight":
-            return 4 * (n(a[0]) + n(a[1]))
+            return n(a[0]) + n(a[1])
         if name in ("bn_add_relu_fwd", "bn_stats_add_relu_fwd", "bn_add_relu_bwd"):
-            return 4 * 3 * n(a[0])
+            return 3 * n(a[0])
         if name in ("bn_relu_pool_fwd", "bn_relu_pool_bwd"):
-            return 4 * n(a[0])
+            return n(a[0])
         if name == "sgd_fused":
-            return 20 * n(a[0])
+            return 5 * n(a[0])
     except Exception:
         pass
     return 0
@@ -209,7 +213,10 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--model", default="M", choices=["S", "M", "L", "XL"],
-                    help="model version (headline: M; 'L' at --size 312 is BASELINE configs[4]'s architecture, fp32 storage here)")
+                    help="model version (headline: M; 'L' at --size 312 with --dtype bf16 is BASELINE configs[4])")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: mixed-storage mode -- the wide tensors inside the bottlenecks stored as bf16, fp32 arithmetic "
+                         "(BASELINE configs[4]; the headline metric is quoted on f32)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -246,7 +253,9 @@ def main():
 
     B, T, H = args.batch, args.frames, args.size
     torch.manual_seed(0)
-    net = x3d.generate_model(args.model, n_classes=400, dropout=0.5, base_bn_splits=max(1, B // 8)).to(dev).train(True)
+    mixed = args.dtype == "bf16"
+    net = x3d.generate_model(args.model, n_classes=400, dropout=0.5, base_bn_splits=max(1, B // 8),
+                             act_dtype=torch.bfloat16 if mixed else torch.float32).to(dev).train(True)
     tr = Trainer(net, lr=0.05, process_group=pg, world_size=world, use_graph=not args.no_graph)
     x = synthetic.synthetic_clips(B, T, H, H, seed=1234 + rank).to(dev)
     y = synthetic.synthetic_labels(B, seed=1234 + rank).to(dev)
@@ -280,7 +289,7 @@ def main():
 
     # the same step with the exact fp32-MFMA backward GEMMs (the switches are read per launch): reported beside the default
     exact = None
-    if not args.no_exact_fp32:
+    if not args.no_exact_fp32 and not mixed:          # the exact fp32-MFMA backward kernels read fp32 tensors only
         os.environ["X3D_DGRAD_F32"] = "1"
         os.environ["X3D_WGRAD_F32"] = "1"
         tr.invalidate_graphs()
@@ -289,9 +298,10 @@ def main():
         del os.environ["X3D_DGRAD_F32"], os.environ["X3D_WGRAD_F32"]
         tr.invalidate_graphs()
 
-    E = algorithmic_elems_M(T, H, args.model)
+    E, Ew = algorithmic_elems_M(T, H, args.model, split=True)
     nparams = sum(p.numel() for p in net.parameters())
-    step_bytes = B * 3 * 4 * E + 20 * nparams
+    # 3 passes (forward, data gradient, weight gradient) over E elements; the wide ones are 2 B in bf16 mode
+    step_bytes = B * 3 * (4 * (E - Ew) + (2 if mixed else 4) * Ew) + 20 * nparams
     out = {
         "metric": "clips/sec X3D-%s fwd+bwd+SGD at multigrid base shape (whole job)" % args.model,
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -300,10 +310,13 @@ def main():
         # bf16 terms, fp32 accumulate: forward 3 terms / 6 products (all 24 significant bits: fp32-level accuracy; the
         # contracting stage 1-2 convs still use the fp32 MFMA), backward 2 terms / 3 products (~2^-16 per product) --
         # value_exact_fp32 is the same job with the exact fp32-MFMA backward kernels
-        "dtype": "f32 (pointwise GEMMs: fp32 operands split into bf16 terms on the MFMA, fp32 accumulate; fwd 3-term = "
-                 "fp32-level, bwd 2-term ~2^-16)", "data": "synthetic",
+        "dtype": ("bf16 storage of the wide bottleneck tensors (conv1 / conv2 outputs and their gradients), every other tensor "
+                  "and all arithmetic f32 (pointwise GEMMs as in the f32 mode)" if mixed else
+                  "f32 (pointwise GEMMs: fp32 operands split into bf16 terms on the MFMA, fp32 accumulate; fwd 3-term = "
+                  "fp32-level, bwd 2-term ~2^-16)"), "data": "synthetic",
         "config": {"workload": "X3D-%s train step B=%d/GPU T=%d H=W=%d, 400 classes, dropout 0.5, SGD momentum" % (args.model, B, T, H),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "storage": "bf16 wide tensors / f32" if mixed else "f32",
                    "launch": "eager" if args.no_graph else "hipGraph(fwd+bwd) + SGD",
                    # storage, forward GEMMs, stencils, BN: fp32.  Backward pointwise GEMMs: fp32 operands split into
                    # hi+lo bf16 (3 MFMA products, fp32 accumulate, ~2^-16 per product; parity-verified)

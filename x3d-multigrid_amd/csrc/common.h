@@ -118,6 +118,51 @@ __device__ __forceinline__ void stx1(void* p, size_t i, int bf, float a) {
     else reinterpret_cast<float*>(p)[i] = a;
 }
 
+// Raw forms for kernels whose storage flag is a RUN-TIME value: the load and the widening are separate calls, so that all
+// loads of a phase can be issued back to back.  (With the one-call forms above the bf16 -> fp32 conversion sits inside the
+// flag's branch, right behind its load: the compiler then waits vmcnt(0) in that branch, once per load -- measured on the
+// batched weight-gradient kernel: 41 vmcnt(0) instead of 5, +44 % time.)  A bf16 payload travels in the low components.
+__device__ __forceinline__ float4 ldx4_raw(const void* p, size_t i, int bf) {
+    if (bf) {
+        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(p) + i);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), 0.f, 0.f);
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ float4 ldo4_raw(const char* base, unsigned eoff, int bf) {
+    if (bf) {
+        const uint2 v = *reinterpret_cast<const uint2*>(base + eoff * 2u);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), 0.f, 0.f);
+    }
+    return *reinterpret_cast<const float4*>(base + eoff * 4u);
+}
+__device__ __forceinline__ float2 ldx2_raw(const void* p, size_t i, int bf) {
+    if (bf) {
+        const unsigned v = *reinterpret_cast<const unsigned*>(reinterpret_cast<const __bf16*>(p) + i);
+        return make_float2(__uint_as_float(v), 0.f);
+    }
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ float ldo1_raw(const char* base, unsigned eoff, int bf) {
+    if (bf) return __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(base + eoff * 2u));
+    return *reinterpret_cast<const float*>(base + eoff * 4u);
+}
+// branch-free widening (selects on a uniform flag)
+__device__ __forceinline__ float4 widen4(float4 r, int bf) {
+    const unsigned a = __float_as_uint(r.x), b = __float_as_uint(r.y);
+    float4 w;
+    w.x = bf ? __uint_as_float(a << 16) : r.x;
+    w.y = bf ? __uint_as_float(a & 0xffff0000u) : r.y;
+    w.z = bf ? __uint_as_float(b << 16) : r.z;
+    w.w = bf ? __uint_as_float(b & 0xffff0000u) : r.w;
+    return w;
+}
+__device__ __forceinline__ float2 widen2(float2 r, int bf) {
+    const unsigned a = __float_as_uint(r.x);
+    return make_float2(bf ? __uint_as_float(a << 16) : r.x, bf ? __uint_as_float(a & 0xffff0000u) : r.y);
+}
+__device__ __forceinline__ float widen1(float r, int bf) { return bf ? __uint_as_float(__float_as_uint(r) << 16) : r; }
+
 // What a consumer reads back from a tensor stored with flag `bf`: statistics that describe a stored tensor (BN sums, BN
 // backward sums) are taken from these values, so the BN that follows sees the statistics of the tensor it normalises.
 __device__ __forceinline__ float stored(float v, int bf) { return bf ? (float)(__bf16)v : v; }

@@ -96,22 +96,32 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[NT]) {
 }
 
 // mixed-storage forms: wave-uniform byte base + element offset, or pointer + element index
+// (raw: the payload is widened later by vwiden -- see ldx4_raw in common.h)
 template <int NT>
 __device__ __forceinline__ void vloado(const char* base, unsigned eoff, int bf, float (&v)[NT]) {
     if (NT == 4) {
-        const float4 t = ldo4(base, eoff, bf);
+        const float4 t = ldo4_raw(base, eoff, bf);
         v[0] = t.x; v[1 % NT] = t.y; v[2 % NT] = t.z; v[3 % NT] = t.w;
     } else {
-        v[0] = ldo1(base, eoff, bf);
+        v[0] = ldo1_raw(base, eoff, bf);
     }
 }
 template <int NT>
 __device__ __forceinline__ void vloadx(const void* p, size_t i, int bf, float (&v)[NT]) {
     if (NT == 4) {
-        const float4 t = ldx4(p, i, bf);
+        const float4 t = ldx4_raw(p, i, bf);
         v[0] = t.x; v[1 % NT] = t.y; v[2 % NT] = t.z; v[3 % NT] = t.w;
     } else {
-        v[0] = ldx1(p, i, bf);
+        v[0] = ldo1_raw(reinterpret_cast<const char*>(p) + i * (bf ? 2u : 4u), 0u, bf);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void vwiden(const float (&r)[NT], int bf, float (&v)[NT]) {
+    if (NT == 4) {
+        const float4 t = widen4(make_float4(r[0], r[1 % NT], r[2 % NT], r[3 % NT]), bf);
+        v[0] = t.x; v[1 % NT] = t.y; v[2 % NT] = t.z; v[3 % NT] = t.w;
+    } else {
+        v[0] = widen1(r[0], bf);
     }
 }
 template <int NT>
@@ -427,18 +437,20 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = min(16 * s + 4 * q + e, K - 1);
-            float b[NT];
+            float b[NT], xw[NT], aw[NT];
+            vwiden<NT>(xd[e], x_bf, xw);
             if (IN == IN_BNBWD) {
+                vwiden<NT>(ad[e], x_bf, aw);
                 const float c0 = Cl[k * 3], c1 = Cl[k * 3 + 1], c2 = Cl[k * 3 + 2];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = fmaf(c0, xd[e][j], fmaf(c1, ad[e][j], c2));
+                for (int j = 0; j < NT; ++j) b[j] = fmaf(c0, xw[j], fmaf(c1, aw[j], c2));
             } else if (IN == IN_AFFACT) {
                 const float sc = Cl[k * 2], sh = Cl[k * 2 + 1];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = act_fwd(fmaf(sc, xd[e][j], sh), A.in_act);
+                for (int j = 0; j < NT; ++j) b[j] = act_fwd(fmaf(sc, xw[j], sh), A.in_act);
             } else {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = xd[e][j];
+                for (int j = 0; j < NT; ++j) b[j] = xw[j];
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -518,6 +530,7 @@ __global__ __launch_bounds__(256, 2) void pw3_kernel(const PwArgs A) {
                 const int ml = mt * 16 + 4 * q + e;
                 const int m = m0 + ml;
                 const bool mv = ml < bm;
+                if (EPI == EPI_ACTBWD) vwiden<NT>(xv[e], ex_bf, xv[e]);
                 float v[NT];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) v[j] = acc[mt][j][e];
@@ -2047,8 +2060,8 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
         for (int i = 0; i < ND; ++i) {
             const int co = min(co0 + row0 + 16 * i, A.Co - 1);
             const size_t base = ((size_t)n * A.Co + co) * (size_t)P + pc;
-            rg[i] = ldx4(A.g, base, ga_bf);
-            ra[i] = ldx4(A.a, base, ga_bf);
+            rg[i] = ldx4_raw(A.g, base, ga_bf);
+            ra[i] = ldx4_raw(A.a, base, ga_bf);
             const float* cb = A.cb + ((size_t)n * A.Co + co) * 3;
             k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
         }
@@ -2068,7 +2081,7 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
             const int ci = min(ci0 + row0 + 16 * i, A.Ci - 1);
             const float* px = A.x + ((size_t)n * A.Ci + ci) * (size_t)A.Pin;
             if (GATHER) rx[i] = make_float4(px[goff[0]], px[goff[1]], px[goff[2]], px[goff[3]]);
-            else rx[i] = ldx4(A.x, ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc, x_bf);
+            else rx[i] = ldx4_raw(A.x, ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc, x_bf);
             if (A.pre != nullptr) {
                 const float2 p2 = *reinterpret_cast<const float2*>(A.pre + ((size_t)n * A.Ci + ci) * 2);
                 sc[i] = p2.x; sh[i] = p2.y;
@@ -2081,7 +2094,8 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const bool ok = pvv && (co0 + row0 + 16 * i < A.Co);
-            const float gv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w}, av[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            const float4 gw = widen4(rg[i], ga_bf), aw = widen4(ra[i], ga_bf);
+            const float gv[4] = {gw.x, gw.y, gw.z, gw.w}, av[4] = {aw.x, aw.y, aw.z, aw.w};
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
@@ -2093,7 +2107,8 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const bool ok = pvv && (ci0 + row0 + 16 * i < A.Ci);
-            float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+            const float4 xw = widen4(rx[i], x_bf);
+            float v[4] = {xw.x, xw.y, xw.z, xw.w};
             if (A.pre != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(sc[i], v[e], sh[i]), A.pre_act);
@@ -2208,15 +2223,15 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
         for (int i = 0; i < ND; ++i) {
             const int co = min(co0 + row0 + RP * i, A.Co - 1);
             const size_t base = ((size_t)n * A.Co + co) * (size_t)P + pc;
-            rg[i] = ldx4(A.g, base, ga_bf);
-            ra[i] = ldx4(A.a, base, ga_bf);
+            rg[i] = ldx4_raw(A.g, base, ga_bf);
+            ra[i] = ldx4_raw(A.a, base, ga_bf);
             const float* cb = A.cb + ((size_t)n * A.Co + co) * 3;
             k0[i] = cb[0]; k1[i] = cb[1]; k2[i] = cb[2];
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int ci = min(ci0 + row0 + RP * i, A.Ci - 1);
-            rx[i] = ldx4(A.x, ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc, x_bf);
+            rx[i] = ldx4_raw(A.x, ((size_t)n * A.Ci + ci) * (size_t)A.Pin + pc, x_bf);
             if (A.pre != nullptr) {
                 const float2 p2 = *reinterpret_cast<const float2*>(A.pre + ((size_t)n * A.Ci + ci) * 2);
                 sc[i] = p2.x; sh[i] = p2.y;
@@ -2230,7 +2245,8 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const bool ok = pvv && (co0 + row0 + RP * i < A.Co);
-            const float gv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w}, av[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            const float4 gw = widen4(rg[i], ga_bf), aw = widen4(ra[i], ga_bf);
+            const float gv[4] = {gw.x, gw.y, gw.z, gw.w}, av[4] = {aw.x, aw.y, aw.z, aw.w};
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
@@ -2242,7 +2258,8 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const bool ok = pvv && (ci0 + row0 + RP * i < A.Ci);
-            float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+            const float4 xw = widen4(rx[i], x_bf);
+            float v[4] = {xw.x, xw.y, xw.z, xw.w};
             if (A.pre != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(sc[i], v[e], sh[i]), A.pre_act);
@@ -2694,9 +2711,13 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
     hipStream_t s = (hipStream_t)stream;
     const bool f32 = getenv("X3D_WGRAD_F32") != nullptr;
     // variant id: bit 0 = CI 64, bit 1 = CO 128, bit 2 = gathered (strided) input; -1 = not a wgrad3 shape
-    // + 10: the same variants for jobs with bf16 tensors (mixed-storage builds of the kernels)
+    // + 10: the mixed-storage builds of the same variants.  Their storage flags are per job, so when ANY job of the call
+    // has a bf16 tensor the whole call runs on them -- one launch per tile variant either way (splitting the batch by
+    // storage type halves the workgroups per launch and pays a ramp and a tail twice)
     static thread_local WgBatch B[20];
     for (int v = 0; v < 20; ++v) { B[v].njobs = 0; B[v].wg0[0] = 0; }
+    bool any_mx = false;
+    for (int i = 0; i < njobs; ++i) any_mx = any_mx || jobs[i].mx != 0;
     auto launch = [&](int vv) -> int {
         WgBatch& b = B[vv];
         if (b.njobs == 0) return X3D_OK;
@@ -2777,13 +2798,11 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
             A.cob = cdiv(J.Cout, wide == 1 ? 256 : 128);
             A.cib = cdiv(J.Cin, wide == 1 ? 96 : 224);
         }
-        if (J.mx) {
-            if (A.strided) {
-                x3d_set_error("pw_bwd_weight_batch: no mixed-storage kernel for a strided conv (Cin=%d Cout=%d)", J.Cin, J.Cout);
-                return X3D_EINVAL;
-            }
-            v += 10;
+        if (J.mx && A.strided) {
+            x3d_set_error("pw_bwd_weight_batch: no mixed-storage kernel for a strided conv (Cin=%d Cout=%d)", J.Cin, J.Cout);
+            return X3D_EINVAL;
         }
+        if (any_mx && !A.strided) v += 10;
         WgBatch& b = B[v];
         b.job[b.njobs] = A;
         b.wg0[b.njobs + 1] = b.wg0[b.njobs] + A.groups * A.cob * A.cib;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const unsigned k = (unsigned)min(row0 + P6_RP * i, K - 1);
-        rx[i] = ldo4(xs, k * (unsigned)P + (unsigned)pc, x_bf);
+        rx[i] = ldo4_raw(xs, k * (unsigned)P + (unsigned)pc, x_bf);      // widened at the staging below
         if (IN_AFF) cf[i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cs) + k * 8u);
     }
     // this wave's A fragments: M tile (block mb, wave), planes behind the fp32 image of the pack
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
         const int row = row0 + P6_RP * i;
         if (row < Kp) {
             const bool ok = pvv && row < K;
-            float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+            const float4 xw = widen4(rx[i], x_bf);
+            float v[4] = {xw.x, xw.y, xw.z, xw.w};
             if (IN_AFF) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(cf[i].x, v[e], cf[i].y), A.in_act);
@@ -243,8 +244,8 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
         for (int i = 0; i < NPASS; ++i) {
             const unsigned k = (unsigned)min(row0 + P6_RP * i, K - 1);
             const unsigned off = k * (unsigned)P + (unsigned)pc;
-            rg[i] = ldo4(gs, off, ga_bf);
-            ra[i] = ldo4(as, off, ga_bf);
+            rg[i] = ldo4_raw(gs, off, ga_bf);
+            ra[i] = ldo4_raw(as, off, ga_bf);
             const float* c3 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(cs) + k * 12u);
             k0[i] = c3[0]; k1[i] = c3[1]; k2[i] = c3[2];
         }
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
             const int row = row0 + P6_RP * i;
             if (row < Kp) {
                 const bool ok = pvv && row < K;
-                const float gv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w}, av[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                const float4 gw = widen4(rg[i], ga_bf), aw = widen4(ra[i], ga_bf);
+                const float gv[4] = {gw.x, gw.y, gw.z, gw.w}, av[4] = {aw.x, aw.y, aw.z, aw.w};
                 bf16x2 he, ho, le, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
             esc[e] = c2.x; esh[e] = c2.y;
         }
         if (EPI != P7_PLAIN) {
-            const float2 t2 = ldx2(A.ex, mrow * (size_t)P + pc2, ex_bf);
+            const float2 t2 = ldx2_raw(A.ex, mrow * (size_t)P + pc2, ex_bf);      // widened in the epilogue
             xv[e][0] = t2.x; xv[e][1] = t2.y;
         }
         if (EPI == P7_RESBWD) {
@@ -371,9 +373,11 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
             float s1 = 0.f, s2 = 0.f;
             if (has_add) { v[0] += av[0] ? adv[e][0] : 0.f; v[1] += av[1] ? adv[e][1] : 0.f; }
             if (EPI != P7_PLAIN) {
+                const float2 xw = widen2(make_float2(xv[e][0], xv[e][1]), EPI == P7_ACTBWD ? ex_bf : 0);
+                const float xwv[2] = {xw.x, xw.y};
 #pragma unroll
                 for (int j2 = 0; j2 < 2; ++j2) {
-                    const float xj = pv ? xv[e][j2] : 0.f;
+                    const float xj = pv ? xwv[j2] : 0.f;
                     if (EPI == P7_RESBWD) v[j2] = (pv && mk[e][j2] > 0.f) ? v[j2] : 0.f;
                     else v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[e], xj, esh[e]), A.e_act) : 0.f;
                     v[j2] = stored(v[j2], y_bf);

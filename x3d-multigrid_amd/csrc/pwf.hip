@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const unsigned k = (unsigned)min(row0 + RP * i, K - 1);
-            rx[i] = ldo4(xs, k * (unsigned)P + (unsigned)pc, x_bf);
+            rx[i] = ldo4_raw(xs, k * (unsigned)P + (unsigned)pc, x_bf);      // widened in store()
             cf[i] = make_float2(1.f, 0.f);
             if (cs != nullptr) cf[i] = ldg_off<float2>(cs, k * 8u);
         }
@@ -491,7 +491,8 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
             const int row = row0 + RP * i;
             if (KP % RP == 0 || row < KP) {
                 const bool ok = pvv && row < K;
-                float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+                const float4 xw = widen4(rx[i], x_bf);
+                float v[4] = {xw.x, xw.y, xw.z, xw.w};
                 if (A.cin != nullptr) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(cf[i].x, v[e], cf[i].y), A.in_act);
