@@ -468,3 +468,20 @@ def test_trainer_bf16_storage_trains():
     print("\nloss fp32 %s\nloss bf16 %s\npeak bytes fp32 %d bf16 %d" % (losses[torch.float32], losses[BF], peak[torch.float32], peak[BF]))
     assert abs(losses[BF][0] - losses[torch.float32][0]) / losses[torch.float32][0] < BF16_RTOL["loss"]
     assert peak[BF] < peak[torch.float32]
+
+
+def test_multigrid_loop_in_bf16_storage(tmp_path, capsys):
+    """The reference's training loop (multigrid shape changes, long-cycle BN-split switches, graph cache, validation phase,
+    checkpoint) with act_dtype=torch.bfloat16: every shape of the schedule has a mixed-storage kernel (odd sizes included)."""
+    _dev()
+    import train_x3d_kinetics_multigrid as tr
+    save = str(tmp_path / "ck_")
+    steps, cps = tr.run(init_lr=0.01, warmup_steps=5, max_epochs=4, batch_size=2, steps=0, max_steps_run=24,
+                        iterations_per_epoch=10, save_model=save, save_every=20, use_graph=True, log_every=10,
+                        val_every=15, val_batches=1, val_batch_size=1, act_dtype=BF)
+    out = capsys.readouterr().out
+    assert steps == 24 and cps > 0
+    assert "nan" not in out.lower()
+    assert out.count(" val after step") == 1
+    import os
+    assert os.path.exists(save + "000020.pt")

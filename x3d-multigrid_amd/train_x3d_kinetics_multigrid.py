@@ -152,7 +152,7 @@ def _save_ckpt(model, optimizer, lr_sched, long_ind, save_model, steps):
 def run(init_lr=INIT_LR, warmup_steps=8000, max_epochs=120, batch_size=BS * BS_UPSCALE, steps=0, max_steps_run=None,
         iterations_per_epoch=None, load_ckpt=None, save_model='models/x3d_multigrid_kinetics_rgb_sgd_',
         save_every=4000, use_graph=True, x3d_version=X3D_VERSION, log_every=20, val_every=None, val_batches=2,
-        val_batch_size=2, val_crops=3, num_steps_per_update=1, clip_size=None):
+        val_batch_size=2, val_crops=3, num_steps_per_update=1, clip_size=None, act_dtype=torch.float32):
     """The reference's training loop (train_x3d_kinetics_multigrid.py:157-292) on synthetic clips.  val_every: run the
     validation phase (`validate`, the reference does it after every 4 training epochs, :195) every that many steps on
     `val_batches` synthetic batches of [val_batch_size, val_crops, 3, T, H, W].
@@ -191,8 +191,10 @@ def run(init_lr=INIT_LR, warmup_steps=8000, max_epochs=120, batch_size=BS * BS_U
 
     base_per_gpu = batch_size // world
     base_splits = max(1, base_per_gpu // CONST_BN_SIZE)
+    # act_dtype=torch.bfloat16: mixed-storage mode (bf16 storage of the wide bottleneck tensors, fp32 arithmetic; not in the
+    # reference, BASELINE config 5)
     model = resnet_x3d.generate_model(x3d_version=x3d_version, n_classes=400, n_input_channels=3, dropout=0.5,
-                                      base_bn_splits=base_splits)
+                                      base_bn_splits=base_splits, act_dtype=act_dtype)
     ck = None
     if load_ckpt is not None:
         ck = torch.load(load_ckpt, map_location='cpu')
@@ -297,10 +299,12 @@ if __name__ == '__main__':
     parser.add_argument('--save-every', type=int, default=4000)
     parser.add_argument('--no-graph', action='store_true')
     parser.add_argument('--version', default=X3D_VERSION)
+    parser.add_argument('--bf16', action='store_true', help='bf16 storage of the wide bottleneck tensors (fp32 arithmetic)')
     args = parser.parse_args()
     if args.gpu is not None:
         os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu
     run(init_lr=(1.6 / 1024) * args.batch, warmup_steps=args.warmup_steps, max_epochs=args.max_epochs,
         batch_size=args.batch, steps=args.start_step, max_steps_run=args.steps,
         iterations_per_epoch=args.iters_per_epoch, load_ckpt=args.load, save_every=args.save_every,
-        use_graph=not args.no_graph, x3d_version=args.version)
+        use_graph=not args.no_graph, x3d_version=args.version,
+        act_dtype=torch.bfloat16 if args.bf16 else torch.float32)
