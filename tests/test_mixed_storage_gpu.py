@@ -396,7 +396,7 @@ def _golden_step(golden_dir, case, dev, act_dtype):
     return g, logits.detach().cpu().numpy()[:, :, 0], loss.item(), grads, net, (x, y, sd, version, S)
 
 
-@pytest.mark.parametrize("case", ["train_M_8x4x64_s2", "train_M_2x8x112_s1", "train_L_4x4x96_s1"])
+@pytest.mark.parametrize("case", ["train_M_8x4x64_s2", "train_M_2x8x112_s1", "train_L_4x4x96_s1", "train_XL_2x4x64_s1"])
 def test_train_step_bf16_storage(golden_dir, case):
     from oracle import x3d_oracle as xo
     from tests import parity
@@ -417,7 +417,7 @@ def test_train_step_bf16_storage(golden_dir, case):
     print("\n[%s, bf16 storage vs the reference's fp32 golden] HIP: %s | rounding oracle: %s | HIP vs rounding oracle: logits %.2e"
           % (case, " ".join("%s %.2e" % kv for kv in hip.items()), " ".join("%s %.2e" % kv for kv in orc.items()),
              parity.rel(logits, o_logits.numpy()[:, :, 0])))
-    depth = 2.0 if version == "L" else 1.0
+    depth = 2.0 if version in ("L", "XL") else 1.0       # 55 blocks (XL also: 630-channel layers on the streaming kernels)
     for k in ("logits", "loss", "grad_norm"):
         assert hip[k] < depth * BF16_RTOL[k], (k, hip[k])
     # the same noise process as the CPU restatement with the same rounding points (independent draws): logits, whose error is

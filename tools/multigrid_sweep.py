@@ -22,7 +22,9 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda:0")
 base = 8
 shapes, _, _ = tr.setup_data(base, 1, 1, 60, 0, 224, [256., 320.], 80, 5)
-model = resnet_x3d.generate_model(x3d_version='M', n_classes=400, dropout=0.5, base_bn_splits=max(1, base // tr.CONST_BN_SIZE))
+DT = torch.bfloat16 if "--bf16" in sys.argv else torch.float32      # --bf16: mixed-storage mode
+model = resnet_x3d.generate_model(x3d_version='M', n_classes=400, dropout=0.5, base_bn_splits=max(1, base // tr.CONST_BN_SIZE),
+                                  act_dtype=DT)
 model.to(dev).train(True)
 opt = Trainer(model, lr=0.0125, use_graph=True)
 gen = torch.Generator(device=dev)

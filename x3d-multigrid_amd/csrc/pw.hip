@@ -1592,9 +1592,10 @@ int launch_pw(PwArgs& A, hipStream_t s) {
     dim3 grid(cdiv(A.tiles, 8) * 8 * A.mblocks, A.N), block(256);
     // mixed storage: only the packed streaming kernel (pw3) of this file reads / writes bf16 tensors
     const bool mx = A.x_bf || A.y_bf || A.ex_bf;
-    if (mx && variant == 2 && A.wp != nullptr) {
-        // large-channel layers whose voxel count is not a multiple of 4 (odd clip sizes): the streaming kernel on the same
-        // 64-voxel tiles, as in the "no packed weights" case below
+    if (mx && variant >= 2 && A.wp != nullptr) {
+        // large-channel layers outside the whole-K kernels of pw6.hip -- voxel count not a multiple of 4 (odd clip sizes), or
+        // K beyond their LDS tile (X3D-XL: 630 channels): the streaming kernel on the same 64-voxel tiles (P2_BN = P4_BN = 64),
+        // as in the "no packed weights" case below
         variant = 1;
         const int mtiles = cdiv(A.M, 16);
         A.mblocks = cdiv(mtiles, 4);
