@@ -365,7 +365,11 @@ def main():
         name, (tms, nbytes, cnt) = dom
         ach = nbytes / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written by tools/collect_traffic.py from PMC passes
+        # written by tools/collect_traffic.py from PMC passes (fp32 mode; the mixed-storage mode has its own collection)
+        tpath = os.path.join(ROOT, "profiles", "r02", "d_traffic_bf16_M.json") if mixed else \
+            os.path.join(ROOT, "profiles", "traffic.json")
+        if not (args.model == "M" and (B, T, H) == (8, 16, 224)):
+            tpath = ""                                              # the PMC collections are of the headline workload only
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")

@@ -249,6 +249,9 @@ def main():
         # the two literal shapes of the config with num_splits = B / 8
         jobs["train_M_64x4x112_s8"] = lambda: train_case(ref, "M", 64, 4, 112, 8)
         jobs["train_M_16x16x224_s2"] = lambda: train_case(ref, "M", 16, 16, 224, 2)
+    if args.big:
+        # BASELINE config 5's literal clip shape (T = 16, H = W = 312) on the "L" architecture, B = 2
+        jobs["train_L_2x16x312_s1"] = lambda: train_case(ref, "L", 2, 16, 312, 1, seed=4, second_draw_threads=1)
     # X3D-XL widths (x3d.py:355) pinned by the reference itself on a tiny clip
     jobs["train_XL_2x4x64_s1"] = lambda: train_case(ref, "XL", 2, 4, 64, 1, seed=2)
     # "X3D-L" (BASELINE config 5's architecture: XL depth, M widths) in fp32 -- the target of the mixed-storage (bf16) mode

@@ -396,7 +396,8 @@ def _golden_step(golden_dir, case, dev, act_dtype):
     return g, logits.detach().cpu().numpy()[:, :, 0], loss.item(), grads, net, (x, y, sd, version, S)
 
 
-@pytest.mark.parametrize("case", ["train_M_8x4x64_s2", "train_M_2x8x112_s1", "train_L_4x4x96_s1", "train_XL_2x4x64_s1"])
+@pytest.mark.parametrize("case", ["train_M_8x4x64_s2", "train_M_2x8x112_s1", "train_L_4x4x96_s1", "train_XL_2x4x64_s1",
+                                  "train_L_2x16x312_s1"])        # the last: BASELINE config 5's literal clip shape, B = 2
 def test_train_step_bf16_storage(golden_dir, case):
     from oracle import x3d_oracle as xo
     from tests import parity

@@ -39,7 +39,8 @@ TRAIN_CASES = ["train_M_2x4x32_s1", "train_M_8x4x64_s2", "train_M_16x2x47_s4", "
                "train_M_64x4x112_s8", "train_M_16x16x224_s2"]
 
 
-@pytest.mark.parametrize("case", TRAIN_CASES + ["train_XL_2x4x64_s1"])        # + X3D-XL widths, pinned by the reference
+# + X3D-XL widths; + the "L" architecture of BASELINE config 5 (XL depth, M widths), incl. its literal clip shape 16 x 312 x 312
+@pytest.mark.parametrize("case", TRAIN_CASES + ["train_XL_2x4x64_s1", "train_L_4x4x96_s1", "train_L_2x16x312_s1"])
 def test_train_step_vs_reference_golden(golden_dir, case):
     dev = _dev()
     g = _golden(golden_dir, case)
