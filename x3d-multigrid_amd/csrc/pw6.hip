@@ -44,8 +44,20 @@ constexpr int P6_MAXPASS = 7;      // K <= 448
 
 __device__ __forceinline__ bf16x8 cat8_(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
+#ifdef X3D_TRACE
+__device__ unsigned long long g_p6trace[16384 * 8];
+extern "C" int x3d_debug_p6trace(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_p6trace), bytes); }
+#define P6T(i) do { if (threadIdx.x == 0) p6t[i] = wall_clock64(); } while (0)
+#else
+#define P6T(i) do { } while (0)
+#endif
+
 template <int IN_AFF, int NPASS, bool MX>
 __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
+#ifdef X3D_TRACE
+    unsigned long long p6t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    P6T(0);
     const int x_bf = MX ? A.x_bf : 0, y_bf = MX ? A.y_bf : 0;      // fp32 build: folded away
     extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,6 +110,11 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
     };
 #pragma unroll
     for (int i = 0; i < 4; ++i) fetch_a(i, ah[i], am[i], al[i]);               // in flight behind the activation burst
+    P6T(1);
+#ifdef X3D_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // trace build: time the round trip alone
+    P6T(2);
+#endif
 
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -128,7 +145,9 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
             *reinterpret_cast<bf16x2*>(&Xl[row * P6_LD + colO]) = lo;
         }
     }
+    P6T(3);
     __syncthreads();
+    P6T(4);
 
     // ---- K loop: B fragments by transposed LDS reads, A fragments through the register ring
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -163,6 +182,7 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
             }
         }
 
+        P6T(5);
         // ---- epilogue: lane (q, r) holds rows 4 q + e of the tile and voxels 2 r (acc[0]), 2 r + 1 (acc[1])
         const int pl = pt + 2 * r;
         const bool pv = pl < P;                   // P even: both voxels or none
@@ -182,7 +202,15 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
             }
         }
     }
+#ifdef X3D_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        p6t[6] = wall_clock64();
+        if (blockIdx.x < 16384) for (int i = 0; i < 8; ++i) g_p6trace[(size_t)blockIdx.x * 8 + i] = p6t[i];
+    }
+#endif
 }
+
 
 
 // ---------------------------------------------------------------------------------------
