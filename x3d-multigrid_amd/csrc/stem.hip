@@ -2,6 +2,7 @@
 // (depthwise temporal 5x1x1, pad (2,0,0); x3d.py:202-208,318), forward and backward.
 // No BN sits between the two convolutions, so conv1_s emits raw output only; conv1_t's
 // epilogue carries the statistics for bn1 (x3d.py:209,319).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -59,73 +60,126 @@ __global__ __launch_bounds__(256) void stem133_fwd_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------
 // conv1_s backward-weight as an MFMA GEMM: dW[co][j] = sum_p dy[co][p] * patch[j][p],
-// j = ci*9 + kh*3 + kw (27 -> 32), co (24 -> 32).  Tiles of 128 voxels are staged in LDS
-// ([32][132] each, im2col built on the fly); each of the 4 waves owns one 16x16 tile of dW.
+// j = ci*9 + kh*3 + kw (27 -> 32), co (24 -> 32).  A tile is a run of 128 output voxels of ONE output row; each of the 4
+// waves owns one 16x16 tile of dW.  dy is staged in LDS ([32][132]); the input is staged as the 3 x Cin input rows the
+// run touches ([ci*3 + kh][264 columns], coalesced float4 row loads, zero outside the image) and the im2col operand is
+// read straight from that image (column 2 p + kw of row (ci, kh)) -- round 1 gathered every tap from global memory,
+// 16 scalar loads per thread and tile at stride 2: 273 MB fetched for 231 MB of tensors, 138 us for a 46 us problem.
 // ---------------------------------------------------------------------------------------
 constexpr int SW_PT = 128, SW_LD = 132;
+constexpr int SX_LD = 264;                 // input columns 2 wo0 - 4 .. 2 wo0 + 259 of a run starting at output column wo0
+constexpr int SX_ROWS = 10;                // 3 x Cin (<= 9) image rows + one row of zeros for the padded j >= 27
 
 __global__ __launch_bounds__(256) void stem133_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ wpartial, int N, int Cin, int Cout,
                                                             int T, int H, int W, int Ho, int Wo, int groups) {
     __shared__ __attribute__((aligned(16))) float Ld[32 * SW_LD];
-    __shared__ __attribute__((aligned(16))) float Lx[32 * SW_LD];
+    __shared__ __attribute__((aligned(16))) float Xt[SX_ROWS * SX_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
     const int wr = wave >> 1, wc = wave & 1;
     const int J = Cin * 9;
     const int HWo = Ho * Wo;
-    const int tiles_per_plane = cdiv(HWo, SW_PT);
+    const int chunks = cdiv(Wo, SW_PT);                    // runs per output row
+    const int tiles_per_plane = Ho * chunks;
     const int total = N * T * tiles_per_plane;
+    const bool vecx = (W & 3) == 0;                        // aligned float4 row loads
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // Staging: thread owns voxel column pp = tid & 127 of the tile and the 16 rows r0, r0 + 2, ... of both LDS images.
-    // All 32 loads of a tile (16 dy values, 16 gathered input taps) are issued together from clamped addresses and masked
-    // when written to LDS; the loads of the NEXT tile are in flight during the MFMAs of the current one.  (The first
-    // version loaded one element per iteration under bounds branches: 16 serial round trips per tile, 224 us per step at
-    // the very end of the backward pass where nothing overlaps it.)
+    for (int i = tid; i < SX_LD; i += 256) Xt[(SX_ROWS - 1) * SX_LD + i] = 0.f;
+
+    // Staging roles.  dy: thread owns voxel column pp = tid & 127 and the 16 rows r0, r0 + 2, ...; input image: float4
+    // granule g = tid + 256 i of the 3 Cin x 66 granules.  The loads of the NEXT tile are in flight during the MFMAs.
+    // Everything that does not depend on the tile is computed once (the first version of this kernel spent most of its
+    // instructions on 64-bit index arithmetic and tile-decoding divisions: it ran at the same 100 us with 2, 3 or 4
+    // workgroups per CU).  A workgroup walks a CONTIGUOUS range of tiles (plane-major, then output row, then run) with
+    // incremental counters; neighbouring output rows share an input row, which then comes from cache.
     const int pp = tid & (SW_PT - 1), r0 = tid >> 7;
-    float dv[16], xv[16];
-    bool dok[16], xok[16];
-    auto load_tile = [&](int tl) {
-        const int plane = tl / tiles_per_plane, pt = (tl - plane * tiles_per_plane) * SW_PT;
-        const int n = plane / T, t = plane - n * T;
-        const int p = pt + pp;
-        const bool pv = p < HWo;
-        const int pc = pv ? p : 0;
-        const int ho = pc / Wo, wo = pc - ho * Wo;
+    constexpr int GPR = SX_LD / 4;                         // granules per image row
+    float dv[16];
+    float4 xr[3];
+    unsigned droff[16];                                    // dy row offsets inside a sample (a sample's dy is < 2^32 elements)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = 2 * i + r0;
-            const int rc = min(row, Cout - 1);
-            dv[i] = dy[(((size_t)n * Cout + rc) * T + t) * (size_t)HWo + pc];
-            dok[i] = pv && row < Cout;
-            const int rj = min(row, J - 1);
-            const int ci = rj / 9, k = rj - ci * 9, kh = k / 3, kw = k - kh * 3;
-            const int hi = 2 * ho - 1 + kh, wi = 2 * wo - 1 + kw;
-            const bool inb = hi >= 0 && hi < H && wi >= 0 && wi < W;
-            const int hic = min(max(hi, 0), H - 1), wic = min(max(wi, 0), W - 1);
-            xv[i] = x[(((size_t)n * Cin + ci) * T + t) * (size_t)H * W + (size_t)hic * W + wic];
-            xok[i] = pv && row < J && inb;
+    for (int i = 0; i < 16; ++i) droff[i] = (unsigned)min(2 * i + r0, Cout - 1) * (unsigned)T * (unsigned)HWo;
+    unsigned xcoff[3];                                     // channel offset of the granule's image row inside a sample
+    int xkh[3], xc4[3];
+    bool xgv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int g = tid + 256 * i;
+        const int row = min(g / GPR, Cin * 3 - 1);
+        xc4[i] = (g - (g / GPR) * GPR) * 4;
+        xkh[i] = row % 3;
+        xcoff[i] = (unsigned)(row / 3) * (unsigned)T * (unsigned)H * (unsigned)W;
+        xgv[i] = g < Cin * 3 * GPR;
+    }
+    const int t_begin = (int)(((long long)blockIdx.x * total) / groups), t_end = (int)(((long long)(blockIdx.x + 1) * total) / groups);
+    // position of the tile being LOADED (one ahead of the tile being computed)
+    int l_plane = t_begin / tiles_per_plane, l_ho, l_ch;
+    {
+        const int rem = t_begin - l_plane * tiles_per_plane;
+        l_ho = rem / chunks;
+        l_ch = rem - l_ho * chunks;
+    }
+    bool l_pv = false;                                     // voxel column of the loaded tile inside the output row
+    auto load_tile = [&]() {
+        const int ho = l_ho, wo0 = l_ch * SW_PT;
+        const int n = l_plane / T, t = l_plane - n * T;
+        const int wo = wo0 + pp;
+        l_pv = wo < Wo;
+        const float* dyb = dy + ((size_t)n * Cout * T + t) * (size_t)HWo + (size_t)ho * Wo + (l_pv ? wo : wo0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dv[i] = dyb[droff[i]];
+        const int wib = 2 * wo0 - 4;                       // first staged input column (multiple of 4)
+        const float* xb = x + ((size_t)n * Cin * T + t) * (size_t)H * W;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int hi = 2 * ho - 1 + xkh[i], wi = wib + xc4[i];
+            const bool rok = xgv[i] && hi >= 0 && hi < H;
+            const float* px = xb + xcoff[i] + (size_t)min(max(hi, 0), H - 1) * W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vecx) {
+                const bool ok = rok && wi >= 0 && wi + 3 < W;            // W % 4 == 0 and wi % 4 == 0: all four columns or none
+                const float4 t4 = *reinterpret_cast<const float4*>(px + (ok ? wi : 0));
+                if (ok) v = t4;
+            } else {
+                const float e0 = px[min(max(wi, 0), W - 1)], e1 = px[min(max(wi + 1, 0), W - 1)];
+                const float e2 = px[min(max(wi + 2, 0), W - 1)], e3 = px[min(max(wi + 3, 0), W - 1)];
+                v.x = (rok && wi >= 0 && wi < W) ? e0 : 0.f;
+                v.y = (rok && wi + 1 >= 0 && wi + 1 < W) ? e1 : 0.f;
+                v.z = (rok && wi + 2 >= 0 && wi + 2 < W) ? e2 : 0.f;
+                v.w = (rok && wi + 3 >= 0 && wi + 3 < W) ? e3 : 0.f;
+            }
+            xr[i] = v;
         }
+        if (++l_ch == chunks) { l_ch = 0; if (++l_ho == Ho) { l_ho = 0; ++l_plane; } }
     };
-    int tl = blockIdx.x;
-    if (tl < total) load_tile(tl);
-    for (; tl < total; tl += groups) {
+    // B operand: lane (q, r) of wave (wr, wc) needs patch row j = wc * 16 + r at voxels kk * 16 + 4 q + e: column
+    // 2 p + kw + 3 of image row (ci, kh) (staged column = input column - wib; input column = 2 (wo0 + p) - 1 + kw)
+    const int jb = wc * 16 + r;
+    const int jci = jb / 9, jk = jb - jci * 9, jkh = jk / 3, jkw = jk - jkh * 3;
+    const float* xrow = Xt + (jb < J ? (jci * 3 + jkh) : (SX_ROWS - 1)) * SX_LD + (jb < J ? jkw + 3 : 0);
+
+    if (t_begin < t_end) load_tile();
+    for (int tl = t_begin; tl < t_end; ++tl) {
         __syncthreads();                       // previous tile's fragments read
+        const bool pv = l_pv;                  // of the tile loaded last = the one staged now
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            Ld[(2 * i + r0) * SW_LD + pp] = dok[i] ? dv[i] : 0.f;
-            Lx[(2 * i + r0) * SW_LD + pp] = xok[i] ? xv[i] : 0.f;
+        for (int i = 0; i < 16; ++i) Ld[(2 * i + r0) * SW_LD + pp] = (pv && 2 * i + r0 < Cout) ? dv[i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int g = tid + 256 * i;
+            if (g < Cin * 3 * GPR) *reinterpret_cast<float4*>(&Xt[(g / GPR) * SX_LD + (g - (g / GPR) * GPR) * 4]) = xr[i];
         }
         __syncthreads();
-        if (tl + groups < total) load_tile(tl + groups);
+        if (tl + 1 < t_end) load_tile();
 #pragma unroll 2
         for (int kk = 0; kk < SW_PT / 16; ++kk) {
             const float4 av = *reinterpret_cast<const float4*>(&Ld[(wr * 16 + r) * SW_LD + kk * 16 + 4 * q]);
-            const float4 bv = *reinterpret_cast<const float4*>(&Lx[(wc * 16 + r) * SW_LD + kk * 16 + 4 * q]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+            const float* xb = xrow + 2 * (kk * 16 + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, xb[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, xb[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, xb[4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, xb[6], acc, 0, 0, 0);
         }
     }
     float* out = wpartial + (size_t)blockIdx.x * Cout * J;
@@ -297,8 +351,9 @@ extern "C" int x3d_stem133_fwd(const float* x, const float* w, float* y, int N, 
 }
 
 extern "C" int x3d_stem_wgrad_groups(int N, int T) {
-    const int g = N * T * 4;
-    return g < 512 ? g : 512;
+    static const int cap = getenv("X3D_STEM_WG_CAP") ? atoi(getenv("X3D_STEM_WG_CAP")) : 512;
+    const int g = N * T * 8;
+    return g < cap ? g : cap;
 }
 
 extern "C" int x3d_stem133_bwd_weight(const float* x, const float* dy, float* wpartial, int N, int Cin, int Cout,
@@ -307,7 +362,7 @@ extern "C" int x3d_stem133_bwd_weight(const float* x, const float* dy, float* wp
     X3D_CHECK_ARG(Cin * 9 <= 32 && Cout <= 32);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     int groups = x3d_stem_wgrad_groups(N, T);
-    const int total = N * T * cdiv(Ho * Wo, SW_PT);
+    const int total = N * T * Ho * cdiv(Wo, SW_PT);
     if (groups > total) groups = total;
     // every group slot of wpartial must be written: launch exactly x3d_stem_wgrad_groups blocks
     groups = x3d_stem_wgrad_groups(N, T);
