@@ -116,13 +116,21 @@ __device__ __forceinline__ void make_chunks(const DwGeom& g, int n, int c0, int 
 // under a divergent branch makes the compiler drain vmcnt -- including the previous step's output
 // stores -- at the top of every T step.
 // MX (mixed-storage build): `base` points at a bf16 array (the float* type is nominal); offsets are in elements.
-template <int NCH, bool VEC, bool MX>
+template <int NCH, int VW, bool MX>
 __device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chunk (&ch)[NCH], int toff, bool tvalid,
                                        float4 (&reg)[NCH]) {
+    // VW: elements per memory instruction -- 4 (rows are multiples of 4 wide: float4), 2 (even widths, e.g. the 14 x 14 planes
+    // of stage 3: float2 pairs; every chunk then holds 2 or 4 valid elements and starts at an even element), 1 (odd widths)
+    constexpr bool VEC = VW == 4, V2 = VW == 2;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const bool ok = tvalid && ch[i].goff >= 0;
-        if (VEC) {
+        if (V2) {
+            const unsigned o = ok ? (unsigned)(ch[i].goff + toff) : 0u, o2 = o + (ch[i].nval > 2 ? 2u : 0u);
+            const float2 a = MX ? ldx2(base, o, 1) : *reinterpret_cast<const float2*>(base + o);
+            const float2 b = MX ? ldx2(base, o2, 1) : *reinterpret_cast<const float2*>(base + o2);
+            reg[i] = make_float4(a.x, a.y, b.x, b.y);
+        } else if (VEC) {
             if (MX) reg[i] = ldx4(base, (size_t)(ok ? ch[i].goff + toff : 0), 1);
             else reg[i] = *reinterpret_cast<const float4*>(base + (ok ? ch[i].goff + toff : 0));
         } else if (MX) {
@@ -142,9 +150,10 @@ __device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chu
 }
 
 // activation applied while storing; everything outside the tensor is exact zero
-template <int NCH, bool VEC>
+template <int NCH, int VW>
 __device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], bool tvalid, float act_lo,
                                           const float4 (&reg)[NCH]) {
+    constexpr bool VEC = VW == 4;
     // Branch-free: the activation in front of this conv is ReLU (x3d.py:147-150) or none, i.e. max(s, act_lo) with
     // act_lo = 0 / -inf (uniform); every element is computed (the registers hold real data from clamped addresses) and
     // the invalid ones are selected to the exact zero of the padding.  The stencils are VALU / issue bound: per-element
@@ -186,8 +195,9 @@ extern "C" int x3d_debug_dwtrace(void* dst, size_t bytes) { return (int)hipMemcp
 #define DTR(i) do { } while (0)
 #endif
 
-template <int NCH, int STRIDE, bool UNI, bool VEC, bool MX>
+template <int NCH, int STRIDE, bool UNI, int VW, bool MX>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
+    constexpr bool VEC = VW == 4, V2 = VW == 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef X3D_TRACE
     unsigned long long dtr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -223,8 +233,8 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     const int plane = g.H * g.W;
 
     float4 reg[NCH], reg1[NCH];
-    fetch4<NCH, VEC, MX>(xb, ch, 0, true, reg);          // need addresses only: in flight during the statistics below
-    fetch4<NCH, VEC, MX>(xb, ch, plane, g.T > 1, reg1);  // (planes 0 and 1 together: one round trip less)
+    fetch4<NCH, VW, MX>(xb, ch, 0, true, reg);          // need addresses only: in flight during the statistics below
+    fetch4<NCH, VW, MX>(xb, ch, plane, g.T > 1, reg1);  // (planes 0 and 1 together: one round trip less)
     if (A.sp != nullptr) {
         // BN finalize of this workgroup's channels for sample n's split (x3d.py:47-58): fp64 sums over N/S samples x
         // stiles partial pairs in a fixed order (identical in every workgroup of a (split, channel)); the tile-0
@@ -290,8 +300,8 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
         __syncthreads();
     }
     const float act_lo = dw_act_lo(A.pre_act);
-    store_act<NCH, VEC>(ring, ch, true, act_lo, reg);
-    store_act<NCH, VEC>(ring + g.slot, ch, g.T > 1, act_lo, reg1);
+    store_act<NCH, VW>(ring, ch, true, act_lo, reg);
+    store_act<NCH, VW>(ring + g.slot, ch, g.T > 1, act_lo, reg1);
     __syncthreads();
 
     // LDS offset of this thread's first window element
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     // fresh store; the store's ack then hides under the next step's stencil.
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
         if (t == 5) DTR(2);
-        fetch4<NCH, VEC, MX>(xb, ch, (t + 2) * plane, t + 2 < g.T, reg);    // in flight during the stencil
+        fetch4<NCH, VW, MX>(xb, ch, (t + 2) * plane, t + 2 < g.T, reg);    // in flight during the stencil
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
             read_plane(ring + (size_t)((t + 1) & 1) * g.slot, wc);
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
         }
         if (t == 5) DTR(3);
         // slot t&1 held plane t, last read one barrier ago -> free for plane t+2
-        store_act<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, act_lo, reg);
+        store_act<NCH, VW>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, act_lo, reg);
         if (t == 5) DTR(4);
         if (valid) {
             float* py = A.y + ybase + (size_t)t * g.Ho * g.Wo;
@@ -374,12 +384,18 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
                 const size_t yi = ybase + (size_t)t * g.Ho * g.Wo;
                 if (VEC) {
                     stx4(A.y, yi, 1, o[0], o[1], o[2], o[3]);
+                } else if (V2) {
+                    stx2(A.y, yi, 1, o[0], o[1]);
+                    if (wo + 2 < g.Wo) stx2(A.y, yi + 2, 1, o[2], o[3]);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) if (wo + i < g.Wo) stx1(A.y, yi + i, 1, o[i]);
                 }
             } else if (VEC) {
                 *reinterpret_cast<float4*>(py) = make_float4(o[0], o[1], o[2], o[3]);
+            } else if (V2) {
+                *reinterpret_cast<float2*>(py) = make_float2(o[0], o[1]);
+                if (wo + 2 < g.Wo) *reinterpret_cast<float2*>(py + 2) = make_float2(o[2], o[3]);
             } else {
                 py[0] = o[0];
                 if (wo + 1 < g.Wo) py[1] = o[1];
@@ -442,10 +458,11 @@ struct DwBwdArgs {
     const float* gamma; const float* save; float* dgamma; float* dbeta;
 };
 
-template <int NCH, bool VEC>
+template <int NCH, int VW>
 __device__ __forceinline__ void store_dy(float* slot, const Chunk (&ch)[NCH], bool tvalid, const float (&k0)[NCH],
                                          const float (&k1)[NCH], const float (&k2)[NCH], const float4 (&rg)[NCH],
                                          const float4 (&ra)[NCH]) {
+    constexpr bool VEC = VW == 4;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         if (ch[i].loff >= 0) {
@@ -461,8 +478,9 @@ __device__ __forceinline__ void store_dy(float* slot, const Chunk (&ch)[NCH], bo
     }
 }
 
-template <int NCH, int STRIDE, bool UNI, bool VEC, bool MX>
+template <int NCH, int STRIDE, bool UNI, int VW, bool MX>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
+    constexpr bool VEC = VW == 4, V2 = VW == 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef X3D_TRACE
     unsigned long long dtr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -513,8 +531,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     const int plane_o = g.Ho * g.Wo;
 
     float4 rg[NCH], ra[NCH];
-    fetch4<NCH, VEC, MX>(gb, ch, 0, true, rg);           // addresses only: in flight during the statistics below
-    fetch4<NCH, VEC, MX>(ab, ch, 0, true, ra);
+    fetch4<NCH, VW, MX>(gb, ch, 0, true, rg);           // addresses only: in flight during the statistics below
+    fetch4<NCH, VW, MX>(ab, ch, 0, true, ra);
     if (A.cb == nullptr) {
         // BN backward finalize of this workgroup's channels (single split; x3d.py:47-58 backward): fp64 sums over all
         // samples x stiles partial pairs in a fixed order (identical in every workgroup of a channel); the (tile 0,
@@ -570,10 +588,10 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     }
     {
         float4 rg1[NCH], ra1[NCH];                       // plane 1 requested before plane 0 is staged: one round trip less
-        fetch4<NCH, VEC, MX>(gb, ch, plane_o, g.T > 1, rg1);
-        fetch4<NCH, VEC, MX>(ab, ch, plane_o, g.T > 1, ra1);
-        store_dy<NCH, VEC>(ring, ch, true, k0, k1, k2, rg, ra);
-        store_dy<NCH, VEC>(ring + g.slot, ch, g.T > 1, k0, k1, k2, rg1, ra1);
+        fetch4<NCH, VW, MX>(gb, ch, plane_o, g.T > 1, rg1);
+        fetch4<NCH, VW, MX>(ab, ch, plane_o, g.T > 1, ra1);
+        store_dy<NCH, VW>(ring, ch, true, k0, k1, k2, rg, ra);
+        store_dy<NCH, VW>(ring + g.slot, ch, g.T > 1, k0, k1, k2, rg1, ra1);
     }
     __syncthreads();
 
@@ -629,6 +647,10 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             if (VEC) {
                 const float4 qv = ldx4(A.x, xi, 1);
                 xnext[0] = qv.x; xnext[1] = qv.y; xnext[2] = qv.z; xnext[3] = qv.w;
+            } else if (V2) {
+                const int rem = g.W - w0;
+                const float2 qa = ldx2(A.x, xi, 1), qb = ldx2(A.x, xi + (rem > 2 ? 2 : 0), 1);
+                xnext[0] = qa.x; xnext[1] = qa.y; xnext[2] = rem > 2 ? qb.x : 0.f; xnext[3] = rem > 2 ? qb.y : 0.f;
             } else {
                 const int rem = g.W - w0;
                 xnext[0] = ldx1(A.x, xi, 1); xnext[1] = ldx1(A.x, xi + (rem > 1 ? 1 : 0), 1);
@@ -639,6 +661,10 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         } else if (VEC) {
             const float4 qv = *reinterpret_cast<const float4*>(px);
             xnext[0] = qv.x; xnext[1] = qv.y; xnext[2] = qv.z; xnext[3] = qv.w;
+        } else if (V2) {
+            const int rem = g.W - w0;          // even; a thread beyond the row (rem <= 0) is not `valid` and reads elements 0..1
+            const float2 qa = *reinterpret_cast<const float2*>(px), qb = *reinterpret_cast<const float2*>(px + (rem > 2 ? 2 : 0));
+            xnext[0] = qa.x; xnext[1] = qa.y; xnext[2] = rem > 2 ? qb.x : 0.f; xnext[3] = rem > 2 ? qb.y : 0.f;
         } else {
             const int rem = g.W - w0;          // independent of t: hoisted (a step that is not loaded reads elements 0..3 of x)
             xnext[0] = px[0]; xnext[1] = px[rem > 1 ? 1 : 0]; xnext[2] = px[rem > 2 ? 2 : 0]; xnext[3] = px[rem > 3 ? 3 : 0];
@@ -651,8 +677,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     // window planes (wa, wb, wc) = dY planes (t-1, t, t+1); time tap kt uses plane t+1-kt
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
         if (t == 5) DTR(2);
-        fetch4<NCH, VEC, MX>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, rg);
-        fetch4<NCH, VEC, MX>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, ra);
+        fetch4<NCH, VW, MX>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, rg);
+        fetch4<NCH, VW, MX>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, ra);
         float xv[4] = {xnext[0], xnext[1], xnext[2], xnext[3]};      // loaded one step ago, complete since the last LDS staging
         load_x(t + 1);                                               // next step's raw input, in flight during the stencil
         float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -717,7 +743,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         }
         if (t == 5) DTR(3);
         // all loads of this step (dY plane t+2, x of step t+1) are consumed before the output store is issued
-        store_dy<NCH, VEC>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, k0, k1, k2, rg, ra);
+        store_dy<NCH, VW>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, k0, k1, k2, rg, ra);
         if (t == 5) DTR(4);
         if (valid) {
             float* po = A.out + xbase + (size_t)t * g.H * g.W;
@@ -725,12 +751,18 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
                 const size_t oi = xbase + (size_t)t * g.H * g.W;
                 if (VEC) {
                     stx4(A.out, oi, 1, o[0], o[1], o[2], o[3]);
+                } else if (V2) {
+                    stx2(A.out, oi, 1, o[0], o[1]);
+                    if (w0 + 2 < g.W) stx2(A.out, oi + 2, 1, o[2], o[3]);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) if (w0 + i < g.W) stx1(A.out, oi + i, 1, o[i]);
                 }
             } else if (VEC) {
                 *reinterpret_cast<float4*>(po) = make_float4(o[0], o[1], o[2], o[3]);
+            } else if (V2) {
+                *reinterpret_cast<float2*>(po) = make_float2(o[0], o[1]);
+                if (w0 + 2 < g.W) *reinterpret_cast<float2*>(po + 2) = make_float2(o[2], o[3]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (w0 + i < g.W) po[i] = o[i];
@@ -826,11 +858,11 @@ static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, h
     return X3D_OK;
 }
 
-#define DW_CASE2(KERNEL, N_, S_, MX_)                                                                  \
-    (uni ? (vec ? dw_launch(KERNEL<N_, S_, true, true, MX_>, ARGS_, GEO_, LDSB_, s)                     \
-                : dw_launch(KERNEL<N_, S_, true, false, MX_>, ARGS_, GEO_, LDSB_, s))                   \
-         : (vec ? dw_launch(KERNEL<N_, S_, false, true, MX_>, ARGS_, GEO_, LDSB_, s)                    \
-                : dw_launch(KERNEL<N_, S_, false, false, MX_>, ARGS_, GEO_, LDSB_, s)))
+#define DW_CASE3(KERNEL, N_, S_, U_, MX_)                                                              \
+    (vw == 4 ? dw_launch(KERNEL<N_, S_, U_, 4, MX_>, ARGS_, GEO_, LDSB_, s)                             \
+             : (vw == 2 ? dw_launch(KERNEL<N_, S_, U_, 2, MX_>, ARGS_, GEO_, LDSB_, s)                  \
+                        : dw_launch(KERNEL<N_, S_, U_, 1, MX_>, ARGS_, GEO_, LDSB_, s)))
+#define DW_CASE2(KERNEL, N_, S_, MX_) (uni ? DW_CASE3(KERNEL, N_, S_, true, MX_) : DW_CASE3(KERNEL, N_, S_, false, MX_))
 #define DW_CASE(KERNEL, N_, S_) (mx ? DW_CASE2(KERNEL, N_, S_, true) : DW_CASE2(KERNEL, N_, S_, false))
 
 #define DW_DISPATCH(KERNEL, ARGS, GEO, LDSB)                                                          \
@@ -838,7 +870,9 @@ static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, h
         const auto& ARGS_ = ARGS; const DwGeom& GEO_ = GEO; const size_t LDSB_ = LDSB;                 \
         const int nch = nch_for(GEO_);                                                                 \
         const bool uni = GEO_.cpb == 1;                                                                \
-        const bool vec = (GEO_.W % 4 == 0) && (GEO_.Wo % 4 == 0);                                      \
+        static const bool no_v2 = getenv("X3D_DW_NO_V2") != nullptr;                                   \
+        const int vw = ((GEO_.W % 4 == 0) && (GEO_.Wo % 4 == 0)) ? 4                                   \
+                     : (((GEO_.W % 2 == 0) && (GEO_.Wo % 2 == 0) && !no_v2) ? 2 : 1);                   \
         int rc_ = X3D_OK;                                                                              \
         if (nch > 8) { x3d_set_error("dw333: row too wide (W=%d)", GEO_.W); return X3D_EINVAL; }       \
         if (GEO_.stride == 1) {                                                                        \
