@@ -17,8 +17,8 @@
 namespace {
 
 constexpr int HB = 8;            // rows per register block
-constexpr int H_CS = 8;          // class slices of the fc2 backward
-constexpr int H_JS = 16;         // hidden-feature slices of the d-pooled reduction
+constexpr int H_CS = 16;         // class slices of the fc2 backward
+constexpr int H_JS = 64;         // hidden-feature slices of the d-pooled reduction
 
 __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long ctr, unsigned idx) {
     // splitmix64 finaliser over (seed, counter, index): uniform 32 bits per element, no state
@@ -279,9 +279,15 @@ __global__ __launch_bounds__(256) void head_sum_slices_kernel(const float* __res
                                                               int slices) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += part[(size_t)k * n + i];
-    out[i] = s;
+    // four independent partial sums (fixed order): the loads of a round are in flight together
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < slices; k += 4) {
+        s0 += part[(size_t)k * n + i]; s1 += part[(size_t)(k + 1) * n + i];
+        s2 += part[(size_t)(k + 2) * n + i]; s3 += part[(size_t)(k + 3) * n + i];
+    }
+    for (; k < slices; ++k) s0 += part[(size_t)k * n + i];
+    out[i] = (s0 + s1) + (s2 + s3);
 }
 
 // Charades localisation losses (train_x3d_charades_loc.py:123,168-189): per-frame logits [B][C][T] are linearly interpolated
