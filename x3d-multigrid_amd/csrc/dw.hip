@@ -876,11 +876,13 @@ static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, h
         int rc_ = X3D_OK;                                                                              \
         if (nch > 8) { x3d_set_error("dw333: row too wide (W=%d)", GEO_.W); return X3D_EINVAL; }       \
         if (GEO_.stride == 1) {                                                                        \
-            if (nch <= 2) rc_ = DW_CASE(KERNEL, 2, 1);                                                 \
+            if (nch <= 1) rc_ = DW_CASE(KERNEL, 1, 1);                                                 \
+            else if (nch <= 2) rc_ = DW_CASE(KERNEL, 2, 1);                                            \
             else if (nch <= 4) rc_ = DW_CASE(KERNEL, 4, 1);                                            \
             else rc_ = DW_CASE(KERNEL, 8, 1);                                                          \
         } else {                                                                                       \
-            if (nch <= 2) rc_ = DW_CASE(KERNEL, 2, 2);                                                 \
+            if (nch <= 1) rc_ = DW_CASE(KERNEL, 1, 2);                                                 \
+            else if (nch <= 2) rc_ = DW_CASE(KERNEL, 2, 2);                                            \
             else if (nch <= 4) rc_ = DW_CASE(KERNEL, 4, 2);                                            \
             else rc_ = DW_CASE(KERNEL, 8, 2);                                                          \
         }                                                                                              \
