@@ -88,17 +88,21 @@ struct Chunk {
 template <int NCH>
 __device__ __forceinline__ void make_chunks(const DwGeom& g, int n, int c0, int row0, int SH, int SW,
                                             const float* pre, Chunk (&ch)[NCH]) {
-    // staged tensor: rows row0 .. row0+IH-1 of a [C][T][SH][SW] volume
+    // staged tensor: rows row0 .. row0+IH-1 of a [C][T][SH][SW] volume.  Only the rows that lie inside the tensor get a chunk
+    // (the others stay the zeros the ring was cleared to): a tile that covers the whole plane stages SH rows, not SH + 2 --
+    // which is what lets the 7 x 7 planes (16 channels x 9 rows x 2 chunks = 288) fit one chunk per thread.
     const int w4n = g.WP / 4 - 2;
-    const int total = g.cpb * g.IH * w4n;
+    const int r_lo = max(0, -row0), r_hi = min(g.IH, SH - row0), nrows = max(r_hi - r_lo, 0);
+    const int total = g.cpb * nrows * w4n;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int idx = i * 256 + threadIdx.x;
         Chunk c;
         c.goff = -1; c.loff = -1; c.nval = 0; c.sc = 1.f; c.sh = 0.f;
         if (idx < total) {
-            const int rowi = idx / w4n, w4 = idx - rowi * w4n;     // rowi = cc*IH + ih
-            const int cc = rowi / g.IH, ih = rowi - cc * g.IH;
+            const int rowk = idx / w4n, w4 = idx - rowk * w4n;     // rowk = cc*nrows + k
+            const int cc = rowk / nrows, ih = r_lo + rowk - cc * nrows;
+            const int rowi = cc * g.IH + ih;
             const int cg = c0 + cc, hi = row0 + ih, w = w4 * 4;
             c.loff = rowi * g.WP + DW_PADL + w;
             if (cg < g.C && hi >= 0 && hi < SH && w < SW) {
@@ -821,7 +825,12 @@ static size_t bwd_lds_bytes(const DwGeom& g) {
     size_t ring = 2 * (size_t)g.slot, red = 29 * 256;
     return (ring > red ? ring : red) * sizeof(float);
 }
-static int nch_for(const DwGeom& g) { return cdiv(g.cpb * g.IH * (g.WP / 4 - 2), 256); }
+// chunk slots per thread: staged rows inside the tensor (see make_chunks) x float4 chunks per row x channels
+static int nch_for(const DwGeom& g, bool backward) {
+    const int SH = backward ? g.Ho : g.H;
+    const int rows = g.tiles == 1 ? (g.IH < SH ? g.IH : SH) : g.IH;
+    return cdiv(g.cpb * rows * (g.WP / 4 - 2), 256);
+}
 
 }  // namespace
 
@@ -865,10 +874,10 @@ static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, h
 #define DW_CASE2(KERNEL, N_, S_, MX_) (uni ? DW_CASE3(KERNEL, N_, S_, true, MX_) : DW_CASE3(KERNEL, N_, S_, false, MX_))
 #define DW_CASE(KERNEL, N_, S_) (mx ? DW_CASE2(KERNEL, N_, S_, true) : DW_CASE2(KERNEL, N_, S_, false))
 
-#define DW_DISPATCH(KERNEL, ARGS, GEO, LDSB)                                                          \
+#define DW_DISPATCH(KERNEL, ARGS, GEO, LDSB, BWD_)                                                    \
     do {                                                                                               \
         const auto& ARGS_ = ARGS; const DwGeom& GEO_ = GEO; const size_t LDSB_ = LDSB;                 \
-        const int nch = nch_for(GEO_);                                                                 \
+        const int nch = nch_for(GEO_, BWD_);                                                           \
         const bool uni = GEO_.cpb == 1;                                                                \
         static const bool no_v2 = getenv("X3D_DW_NO_V2") != nullptr;                                   \
         const int vw = ((GEO_.W % 4 == 0) && (GEO_.Wo % 4 == 0)) ? 4                                   \
@@ -908,7 +917,7 @@ extern "C" int x3d_dw333_fwd(const void* x, const float* w, void* y, int N, int 
     const size_t ldsb = fwd_lds_bytes(A.g);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_fwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
-    DW_DISPATCH(dw_fwd_kernel, A, A.g, ldsb);
+    DW_DISPATCH(dw_fwd_kernel, A, A.g, ldsb, false);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
@@ -933,7 +942,7 @@ extern "C" int x3d_dw333_fwd_stats(const void* x, const float* w, void* y, int N
     const size_t ldsb = fwd_lds_bytes(A.g);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_fwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
-    DW_DISPATCH(dw_fwd_kernel, A, A.g, ldsb);
+    DW_DISPATCH(dw_fwd_kernel, A, A.g, ldsb, false);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
@@ -955,7 +964,7 @@ extern "C" int x3d_dw333_bwd(const void* g, const void* a, const float* cb, cons
     const size_t ldsb = bwd_lds_bytes(A.geo);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_bwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
-    DW_DISPATCH(dw_bwd_kernel, A, A.geo, ldsb);
+    DW_DISPATCH(dw_bwd_kernel, A, A.geo, ldsb, true);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
@@ -979,7 +988,7 @@ extern "C" int x3d_dw333_bwd_stats(const void* g, const void* a, const float* sp
     const size_t ldsb = bwd_lds_bytes(A.geo);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_bwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
-    DW_DISPATCH(dw_bwd_kernel, A, A.geo, ldsb);
+    DW_DISPATCH(dw_bwd_kernel, A, A.geo, ldsb, true);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
