@@ -573,11 +573,25 @@ __global__ __launch_bounds__(256) void bn_stats_add_relu_fwd_kernel(
     // 2. statistics of (split j, channel c)
     const int ns = N / S, ne = ns * tiles;
     double s1 = 0.0, s2 = 0.0;
-    for (int e = tid; e < ne; e += 256) {
-        const int k = e / tiles, t = e - k * tiles;
-        const float2 v = *reinterpret_cast<const float2*>(partial + (((size_t)(j + k * S) * C + c) * tiles + t) * 2);
-        s1 += (double)v.x;
-        s2 += (double)v.y;
+    {
+        // four pairs in flight per thread (a row of 784-1568 pairs was 4-7 serial round trips in front of the barrier);
+        // fixed order: four strided partial sums, then a fixed tree
+        auto ldp = [&](int e) -> float2 {
+            const int ec = e < ne ? e : 0;
+            const int k = ec / tiles, t = ec - k * tiles;
+            const float2 v = *reinterpret_cast<const float2*>(partial + (((size_t)(j + k * S) * C + c) * tiles + t) * 2);
+            return e < ne ? v : make_float2(0.f, 0.f);
+        };
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3_ = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        for (int e = tid; e < ne; e += 1024) {
+            const float2 v0 = ldp(e), v1 = ldp(e + 256), v2 = ldp(e + 512), v3 = ldp(e + 768);
+            a0 += (double)v0.x; b0 += (double)v0.y;
+            a1 += (double)v1.x; b1 += (double)v1.y;
+            a2 += (double)v2.x; b2 += (double)v2.y;
+            a3_ += (double)v3.x; b3 += (double)v3.y;
+        }
+        s1 = (a0 + a1) + (a2 + a3_);
+        s2 = (b0 + b1) + (b2 + b3);
     }
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((tid & 63) == 0) { redd[(tid >> 6) * 2] = s1; redd[(tid >> 6) * 2 + 1] = s2; }
