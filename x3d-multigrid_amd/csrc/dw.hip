@@ -253,13 +253,23 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
             const int ccs = cb0 + wave / wpc, sub = wave % wpc;
             if (ccs < g.cpb) {
                 const int cg = min(c0 + ccs, g.C - 1);
-                double s1 = 0.0, s2 = 0.0;
-                for (int e = sub * 64 + lane; e < ne; e += 64 * wpc) {
-                    const int k = e / A.stiles, t = e - k * A.stiles;
+                // four pairs in flight per lane (a channel's 520-784 pairs were up to twelve serial round trips); fixed order
+                const int st = 64 * wpc;
+                auto ldp = [&](int e) -> float2 {
+                    const int ec = e < ne ? e : 0;
+                    const int k = ec / A.stiles, t = ec - k * A.stiles;
                     const float2 v = *reinterpret_cast<const float2*>(A.sp + (((size_t)(j + k * A.S) * g.C + cg) * A.stiles + t) * 2);
-                    s1 += (double)v.x;
-                    s2 += (double)v.y;
+                    return e < ne ? v : make_float2(0.f, 0.f);
+                };
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+                for (int e = sub * 64 + lane; e < ne; e += 4 * st) {
+                    const float2 v0 = ldp(e), v1 = ldp(e + st), v2 = ldp(e + 2 * st), v3 = ldp(e + 3 * st);
+                    a0 += (double)v0.x; b0 += (double)v0.y;
+                    a1 += (double)v1.x; b1 += (double)v1.y;
+                    a2 += (double)v2.x; b2 += (double)v2.y;
+                    a3 += (double)v3.x; b3 += (double)v3.y;
                 }
+                double s1 = (a0 + a1) + (a2 + a3), s2 = (b0 + b1) + (b2 + b3);
                 for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
                 if (lane == 0) { dred[(ccs * 4 + sub) * 2] = s1; dred[(ccs * 4 + sub) * 2 + 1] = s2; }
             }
@@ -550,13 +560,22 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             const int ccs = cb0 + wave / wpc, sub = wave % wpc;
             if (ccs < g.cpb) {
                 const int cg = min(c0 + ccs, g.C - 1);
-                double s1 = 0.0, s2 = 0.0;
-                for (int e = sub * 64 + lane; e < ne; e += 64 * wpc) {
-                    const int k = e / A.stiles, t = e - k * A.stiles;
+                const int st = 64 * wpc;                       // four pairs in flight per lane (see dw_fwd_kernel)
+                auto ldp = [&](int e) -> float2 {
+                    const int ec = e < ne ? e : 0;
+                    const int k = ec / A.stiles, t = ec - k * A.stiles;
                     const float2 v = *reinterpret_cast<const float2*>(A.sp + (((size_t)k * g.C + cg) * A.stiles + t) * 2);
-                    s1 += (double)v.x;
-                    s2 += (double)v.y;
+                    return e < ne ? v : make_float2(0.f, 0.f);
+                };
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+                for (int e = sub * 64 + lane; e < ne; e += 4 * st) {
+                    const float2 v0 = ldp(e), v1 = ldp(e + st), v2 = ldp(e + 2 * st), v3 = ldp(e + 3 * st);
+                    a0 += (double)v0.x; b0 += (double)v0.y;
+                    a1 += (double)v1.x; b1 += (double)v1.y;
+                    a2 += (double)v2.x; b2 += (double)v2.y;
+                    a3 += (double)v3.x; b3 += (double)v3.y;
                 }
+                double s1 = (a0 + a1) + (a2 + a3), s2 = (b0 + b1) + (b2 + b3);
                 for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
                 if (lane == 0) { dred[(ccs * 4 + sub) * 2] = s1; dred[(ccs * 4 + sub) * 2 + 1] = s2; }
             }
