@@ -2435,6 +2435,14 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     double s = 0.0;
     if (i < n) {
         int g = wave;
+        for (; g + 28 < groups; g += 32) {           // eight rows in flight per wave (512 groups: 16 round trips instead of 32)
+            const float v0 = partial[(size_t)g * n + i], v1 = partial[(size_t)(g + 4) * n + i];
+            const float v2 = partial[(size_t)(g + 8) * n + i], v3 = partial[(size_t)(g + 12) * n + i];
+            const float v4 = partial[(size_t)(g + 16) * n + i], v5 = partial[(size_t)(g + 20) * n + i];
+            const float v6 = partial[(size_t)(g + 24) * n + i], v7 = partial[(size_t)(g + 28) * n + i];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+            s += ((double)v4 + (double)v5) + ((double)v6 + (double)v7);
+        }
         for (; g + 12 < groups; g += 16) {
             const float v0 = partial[(size_t)g * n + i], v1 = partial[(size_t)(g + 4) * n + i];
             const float v2 = partial[(size_t)(g + 8) * n + i], v3 = partial[(size_t)(g + 12) * n + i];
@@ -2472,6 +2480,14 @@ __global__ __launch_bounds__(256) void reduce_partials_batch_kernel(const Reduce
     double s = 0.0;
     if (i < n) {
         int g = wave;
+        for (; g + 28 < groups; g += 32) {           // eight rows in flight per wave (512 groups: 16 round trips instead of 32)
+            const float v0 = partial[(size_t)g * n + i], v1 = partial[(size_t)(g + 4) * n + i];
+            const float v2 = partial[(size_t)(g + 8) * n + i], v3 = partial[(size_t)(g + 12) * n + i];
+            const float v4 = partial[(size_t)(g + 16) * n + i], v5 = partial[(size_t)(g + 20) * n + i];
+            const float v6 = partial[(size_t)(g + 24) * n + i], v7 = partial[(size_t)(g + 28) * n + i];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+            s += ((double)v4 + (double)v5) + ((double)v6 + (double)v7);
+        }
         for (; g + 12 < groups; g += 16) {
             const float v0 = partial[(size_t)g * n + i], v1 = partial[(size_t)(g + 4) * n + i];
             const float v2 = partial[(size_t)(g + 8) * n + i], v3 = partial[(size_t)(g + 12) * n + i];
