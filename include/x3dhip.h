@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define X3D_ABI_VERSION 5
+#define X3D_ABI_VERSION 6
 
 #define X3D_OK 0
 #define X3D_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
@@ -54,6 +54,21 @@ extern "C" {
 
 int x3d_abi_version(void);
 const char* x3d_last_error(void);
+
+/* Tuning / A-B options (ABI 6).  The reference has no counterpart (its only knobs are the module constants of
+ * train_x3d_kinetics_multigrid.py:49-61); these select between kernels of this library that compute the same function.
+ * Options are process-wide integers, read at CALL time by every entry point and tile-count query (so a query and the
+ * launch it sizes buffers for must not straddle a change); each starts from its default or from the environment variable
+ * of the same meaning (X3D_FB_GRID, X3D_DGRAD_F32, ...: DESIGN.md section 7).  Names: x3d_option_name(0 .. x3d_option_count()-1):
+ *   fb_grid, pw_pgrid, pw_nt4_min, pw_no_persist, dw_th, dw_balance, dw_no_v2, no_pw6, no_pw7, no_pwfs, dgrad_f32,
+ *   wgrad_f32, bwd_terms (3 = fp32-level three-term bf16 split of the backward GEMM operands, 2 = two-term, ~2^-16),
+ *   no_wgrad4, wg_cpw, wg_cap, stem_wg_cap.
+ * Unknown name or out-of-range value: X3D_EINVAL. */
+int x3d_set_option(const char* name, int value);
+int x3d_get_option(const char* name, int* value);
+int x3d_reset_options(void);
+int x3d_option_count(void);
+const char* x3d_option_name(int index);
 
 /* ------------------------------------------------------------------------------------
  * Pointwise 1x1x1 convolution  (conv1x1x1 x3d.py:98-103; Bottleneck.conv1/conv3 :112,116;

@@ -16,6 +16,36 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of the GPU suite (the driver runs `-m gpu -x`): localising tests first, so that one whole-network failure cannot hide
+# the kernel-level evidence -- C-ABI kernel parity (test_ops_gpu), then the block-level checks of test_model_gpu, then the
+# whole-network goldens from the smallest clip to the largest, the trainer / graph / RCCL tests, the mixed-storage mode,
+# the input pipeline and the two-rank bench.  CPU tests keep their collection order (they sort in front: key 0).
+_FILE_RANK = {"test_ops_gpu.py": 1, "test_model_gpu.py": 2, "test_train_gpu.py": 4, "test_mixed_storage_gpu.py": 5,
+              "test_input_gpu.py": 6, "test_bench_ddp_gpu.py": 7}
+_GOLDEN_TESTS = ("test_train_step_vs_reference_golden", "test_loc_head_vs_reference_golden", "test_eval_forward_config1_S",
+                 "test_xl_widths_vs_oracle")
+
+
+def _clip_elems(nodeid):
+    """B*T*H*W of a golden case id like train_M_2x4x158_s2 (0 when the id has no shape)."""
+    import re
+    m = re.search(r"_(\d+)x(\d+)x(\d+)(?:_|\]|$)", nodeid)
+    return int(m.group(1)) * int(m.group(2)) * int(m.group(3)) ** 2 if m else 0
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(it_idx):
+        idx, it = it_idx
+        if it.get_closest_marker("gpu") is None:
+            return (0, 0, 0, idx)
+        fname = os.path.basename(str(it.fspath))
+        rank = _FILE_RANK.get(fname, 3)
+        if fname == "test_model_gpu.py" and it.name.split("[")[0] in _GOLDEN_TESTS:
+            return (3, 1, _clip_elems(it.nodeid), idx)         # whole-network goldens: after the block tests, small -> large
+        return (rank, 0, 0, idx)
+    items[:] = [it for _, it in sorted(enumerate(items), key=key)]
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

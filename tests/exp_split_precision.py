@@ -91,6 +91,6 @@ for case in cases:
         status = "FAIL"
     print(case, "nb", NB, "logits %.2e loss %.2e" % (e, el), status)
     if isinstance(rep, dict):
-        print("   ", {k: float("%.3g" % v) for k, v in rep.items()})
+        print("   ", parity.fmt(rep))
     else:
         print("   ", rep)

@@ -441,7 +441,7 @@ def test_fp32_mode_is_untouched_by_the_mixed_storage_build(golden_dir):
     g, logits, loss, grads, _, _ = _golden_step(golden_dir, "train_L_4x4x96_s1", dev, torch.float32)
     parity.check_forward(logits, loss, g)
     rep = parity.check_grads(grads, g, synthetic.gradient_sketch)
-    print("\n[train_L_4x4x96_s1 fp32] " + " ".join("%s=%.2e" % kv for kv in sorted(rep.items())))
+    print("\n[train_L_4x4x96_s1 fp32] " + parity.fmt(rep))
 
 
 def test_trainer_bf16_storage_trains():

@@ -61,7 +61,7 @@ def test_train_step_vs_reference_golden(golden_dir, case):
     parity.check_bn_stats({k: v.cpu().numpy() for k, v in sd.items() if v.ndim}, g)
     assert int(sd["bn1.split_bn.num_batches_tracked"]) == 1
     print("\n[%s] logits %.2e loss %.2e | %s" % (case, e_log, e_loss,
-          " ".join("%s=%.2e" % kv for kv in sorted(rep.items()))))
+          parity.fmt(rep)))
     # eval after aggregation on the same clip (x3d.py:306-313; train...:203-206)
     net.train(False)
     assert net.aggregate_sub_bn_stats() == int(g["n_agg"])
@@ -74,6 +74,46 @@ def test_train_step_vs_reference_golden(golden_dir, case):
     with torch.no_grad():
         ev = net(x)
     assert parity.rel(ev.cpu().numpy()[:, :, 0], g["eval_logits"]) < parity.RTOL
+
+
+@pytest.mark.parametrize("case", ["train_M_2x4x158_s2", "train_M_8x4x64_s2"])
+def test_train_step_is_bitwise_reproducible_under_poisoned_allocations(golden_dir, case):
+    """The same step three times in one process: as is, with every buffer the ops allocate NaN-filled first
+    (x3dhip.ops.set_poison), and with the caching allocator's free blocks left full of finite garbage.  Logits and
+    all 316 gradients must be BITWISE equal: a statistics / weight-gradient slot that is summed but never written, or a
+    result that depends on what memory held before, cannot hide behind a tolerance (GPUTEST_r02: train_M_2x4x158_s2 was
+    green on one box and 6.4e-3 off on another)."""
+    from x3dhip import ops
+    dev = _dev()
+    g = _golden(golden_dir, case)
+    B, T, H, S = [int(v) for v in g["shape"]]
+    x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1])).to(dev)
+    y = synthetic.synthetic_labels(B, seed=int(g["seed"][1])).to(dev)
+
+    def run(poison, dirty):
+        prev = ops.set_poison(poison)
+        try:
+            net = _build(case.split("_")[1], S, dev, int(g["seed"][0]))
+            net.train(True)
+            if dirty:
+                junk = [torch.empty(n, device=dev).uniform_(-1e3, 1e3) for n in (1 << 25, 1 << 23, 1 << 21, 1 << 19, 1 << 17) for _ in range(3)]
+                del junk
+            logits = net(x)
+            loss = torch.nn.CrossEntropyLoss()(logits, y)
+            loss.backward()
+            torch.cuda.synchronize()
+            # (the loss value itself comes from ATen's nll_loss2d here -- float atomics, not bitwise stable -- and is not compared)
+            return [logits.detach().clone()] + [p.grad.detach().clone() for p in net.parameters()], \
+                [k for k, _ in net.named_parameters()]
+        finally:
+            ops.set_poison(prev)
+
+    ref, names = run(False, False)
+    assert all(bool(torch.isfinite(t).all()) for t in ref)
+    for poison, dirty in ((True, False), (False, True)):
+        cur, _ = run(poison, dirty)
+        bad = [(["logits"] + names)[i] for i, (a, b) in enumerate(zip(ref, cur)) if not torch.equal(a, b)]
+        assert not bad, "poison=%s dirty=%s: %d tensors differ, first %s" % (poison, dirty, len(bad), bad[:8])
 
 
 def test_loc_head_vs_reference_golden(golden_dir):

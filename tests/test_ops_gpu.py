@@ -70,6 +70,19 @@ PW_CASES = [
     # of a mapped segment (gpurun_out/all23.log); every kernel has clamped the tile index since 3e45adf
     (2, 192, 432, 13, 5, 5, 1, 1),
     (2, 432, 192, 13, 5, 5, 1, 2),
+    # the pointwise layers of X3D-M at the multigrid clip (2, 4, 158, 158) with 2 BN splits (GPUTEST_r02's red case
+    # train_M_2x4x158_s2): planes 79 -> 40 -> 20 -> 10 -> 5, P = 24 964 / 6400 / 1600 / 400 / 100.  P = 100 ends in a 4-voxel
+    # tile of the 32-voxel whole-K kernels; the downsample convs gather from odd planes (79 -> 40)
+    (2, 24, 24, 4, 79, 79, 2, 1),     # layer1.0 downsample: strided gather from the odd 79 x 79 plane
+    (2, 24, 48, 4, 40, 40, 2, 1),     # layer2.0 downsample
+    (2, 48, 216, 4, 20, 20, 1, 1),    # layer3.0 conv1
+    (2, 48, 96, 4, 20, 20, 2, 1),     # layer3.0 downsample
+    (2, 216, 96, 4, 10, 10, 1, 2),    # layer3.x conv3 (P = 400: 13 tiles of 32, tail of 16)
+    (2, 96, 216, 4, 10, 10, 1, 0),    # layer3.x conv1
+    (2, 96, 432, 4, 10, 10, 1, 0),    # layer4.0 conv1
+    (2, 96, 192, 4, 10, 10, 2, 1),    # layer4.0 downsample
+    (2, 432, 192, 4, 5, 5, 1, 2),     # layer4.x conv3 (P = 100: 4 tiles of 32, tail of 4)
+    (2, 192, 432, 4, 5, 5, 1, 0),     # layer4.x conv1 / conv5
 ]
 
 
@@ -183,8 +196,17 @@ FUSED_CASES = [
     (2, 108, 48, 2, 14, 14, 2),     # conv3 of stage 2 (64 x 128), P = 392: tail of 8 voxels
     (2, 24, 108, 4, 12, 12, 1),     # layer2.0 conv1 (128 x 32)
     (2, 40, 60, 2, 10, 10, 2),      # padded to (64, 64)
-    (9, 24, 54, 2, 8, 8, 1),        # more chunks than one round of a small grid (X3D_FB_GRID is 512: 18 chunks)
+    (9, 24, 54, 2, 8, 8, 1),        # 18 chunks on a grid of 18
     (1, 60, 20, 1, 2, 2, 0),        # P = 4: a single partial chunk
+    # N * ceil(P / 64) > 512: the PERSISTENT multi-chunk loop (a workgroup walks chunks c, c + 512, ...; one-chunk-ahead
+    # register prefetch, LDS images re-staged per chunk) -- until round 3 only whole-network tests reached it.  These are the
+    # stage 1-2 layers of train_M_2x4x158_s2 (GPUTEST_r02's red case):
+    (2, 24, 54, 4, 79, 79, 1),      # layer1.0 conv1: P = 24 964 -> 782 chunks, last chunk 4 voxels, stride-2 addend on an odd plane
+    (2, 54, 24, 4, 40, 40, 2),      # layer1.x conv3: P = 6400 -> 200 chunks
+    (2, 24, 108, 4, 40, 40, 1),     # layer2.0 conv1 (stride-2 addend 40 -> 20)
+    (2, 108, 48, 4, 20, 20, 2),     # layer2.x conv3
+    (12, 48, 108, 4, 20, 20, 1),    # layer2.x conv1 at N = 12: 300 chunks; and
+    (24, 54, 24, 4, 40, 40, 2),     # 2400 chunks on 512 workgroups: 4-5 chunks per workgroup, uneven tail round
 ]
 
 
@@ -277,6 +299,16 @@ DW_CASES = [
     (8, 108, 2, 28, 28, 1),   # base-shape stage-2 plane at full N, C (the tile-count queries take N, C: ABI 3)
     (8, 54, 2, 56, 56, 1),    # base-shape stage-1 plane
     (4, 216, 2, 40, 40, 1),   # 40 rows: balanced tiles of 14, 14, 12 rows
+    # the channelwise layers of train_M_2x4x158_s2 (GPUTEST_r02's red case), N = 2, T = 4: odd 79-wide plane at stride 2 over
+    # several row tiles (element-wise VW = 1 form), then the 40 -> 20 -> 10 -> 5 chain
+    (2, 54, 4, 79, 79, 2),    # layer1.0: 79 -> 40, VW = 1, 7 row tiles backward
+    (2, 54, 4, 40, 40, 1),    # layer1.x
+    (2, 108, 4, 40, 40, 2),   # layer2.0: 40 -> 20
+    (2, 108, 4, 20, 20, 1),
+    (2, 216, 4, 20, 20, 2),   # layer3.0: 20 -> 10 (VW = 2)
+    (2, 216, 4, 10, 10, 1),
+    (2, 432, 4, 10, 10, 2),   # layer4.0: 10 -> 5 (VW = 1: odd output width)
+    (2, 432, 4, 5, 5, 1),
 ]
 
 
@@ -346,7 +378,7 @@ def test_dw333_fwd_stats_equals_finalize_then_conv(case, S):
         assert _rel(part.double().sum(2), p_ref.double().sum(2)) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 4, 16, 16), (1, 3, 3, 15, 11), (1, 3, 2, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 3, 4, 16, 16), (1, 3, 3, 15, 11), (1, 3, 2, 64, 64), (2, 3, 4, 158, 158)])
 def test_stem(shape):
     from x3dhip import ops
     dev = _dev()

@@ -13,3 +13,95 @@ void x3d_set_error(const char* fmt, ...) {
 
 extern "C" const char* x3d_last_error(void) { return g_err; }
 extern "C" int x3d_abi_version(void) { return X3D_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------
+// Tuning / A-B options (include/x3dhip.h: x3d_set_option).  ONE table, read at call time by every entry point through
+// x3d_opt(): a test can flip an option in-process (e.g. a small persistent grid to drive the multi-chunk loops of the fused
+// kernels with small tensors) and the tile-count queries see the same value as the launch that follows.  Each option
+// takes its initial value from an environment variable once, at first use (the round 1-2 switches keep working from the
+// shell); nothing else in the library calls getenv.
+// ---------------------------------------------------------------------------------------
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+
+namespace {
+struct OptDef { const char* name; const char* env; int def; int env_flag; };   // env_flag: the variable's presence means 1
+const OptDef kOpts[X3D_OPT_COUNT] = {
+    /* X3D_OPT_FB_GRID        */ {"fb_grid", "X3D_FB_GRID", 512, 0},
+    /* X3D_OPT_PW_PGRID       */ {"pw_pgrid", "X3D_PW_PGRID", 512, 0},
+    /* X3D_OPT_PW_NT4_MIN     */ {"pw_nt4_min", "X3D_PW_NT4_MIN", 256, 0},
+    /* X3D_OPT_PW_NO_PERSIST  */ {"pw_no_persist", "X3D_PW_NO_PERSIST", 0, 1},
+    /* X3D_OPT_DW_TH          */ {"dw_th", "X3D_DW_TH", 16, 0},
+    /* X3D_OPT_DW_BALANCE     */ {"dw_balance", "X3D_DW_BALANCE", 1, 0},
+    /* X3D_OPT_DW_NO_V2       */ {"dw_no_v2", "X3D_DW_NO_V2", 0, 1},
+    /* X3D_OPT_NO_PW6         */ {"no_pw6", "X3D_NO_PW6", 0, 1},
+    /* X3D_OPT_NO_PW7         */ {"no_pw7", "X3D_NO_PW7", 0, 1},
+    /* X3D_OPT_NO_PWFS        */ {"no_pwfs", "X3D_NO_PWFS", 0, 1},
+    /* X3D_OPT_DGRAD_F32      */ {"dgrad_f32", "X3D_DGRAD_F32", 0, 1},
+    /* X3D_OPT_WGRAD_F32      */ {"wgrad_f32", "X3D_WGRAD_F32", 0, 1},
+    /* X3D_OPT_BWD_TERMS      */ {"bwd_terms", "X3D_BWD_TERMS", 3, 0},
+    /* X3D_OPT_NO_WGRAD4      */ {"no_wgrad4", "X3D_NO_WGRAD4", 0, 1},
+    /* X3D_OPT_WG_CPW         */ {"wg_cpw", "X3D_WG_CPW", 8, 0},
+    /* X3D_OPT_WG_CAP         */ {"wg_cap", "X3D_WG_CAP", 256, 0},
+    /* X3D_OPT_STEM_WG_CAP    */ {"stem_wg_cap", "X3D_STEM_WG_CAP", 512, 0},
+};
+std::atomic<int> g_opt[X3D_OPT_COUNT];
+std::once_flag g_opt_once;
+
+int opt_initial(const OptDef& d) {
+    const char* e = getenv(d.env);
+    if (e == nullptr) return d.def;
+    return d.env_flag ? 1 : atoi(e);
+}
+void opt_init() {
+    for (int i = 0; i < X3D_OPT_COUNT; ++i) g_opt[i].store(opt_initial(kOpts[i]), std::memory_order_relaxed);
+}
+int opt_find(const char* name) {
+    if (name == nullptr) return -1;
+    for (int i = 0; i < X3D_OPT_COUNT; ++i) if (strcmp(name, kOpts[i].name) == 0) return i;
+    return -1;
+}
+bool opt_valid(int id, int v) {
+    switch (id) {
+        case X3D_OPT_FB_GRID: case X3D_OPT_PW_PGRID: case X3D_OPT_WG_CAP: case X3D_OPT_STEM_WG_CAP: return v >= 1 && v <= 65535;
+        case X3D_OPT_PW_NT4_MIN: return v >= 0;
+        case X3D_OPT_DW_TH: return v >= 1 && v <= 16;
+        case X3D_OPT_WG_CPW: return v >= 1 && v <= 4096;
+        case X3D_OPT_BWD_TERMS: return v == 2 || v == 3;
+        default: return v == 0 || v == 1;
+    }
+}
+}  // namespace
+
+int x3d_opt(int id) {
+    std::call_once(g_opt_once, opt_init);
+    return g_opt[id].load(std::memory_order_relaxed);
+}
+
+extern "C" int x3d_set_option(const char* name, int value) {
+    std::call_once(g_opt_once, opt_init);
+    const int id = opt_find(name);
+    if (id < 0) { x3d_set_error("x3d_set_option: unknown option '%s'", name ? name : "(null)"); return X3D_EINVAL; }
+    if (!opt_valid(id, value)) { x3d_set_error("x3d_set_option: value %d is out of range for '%s'", value, name); return X3D_EINVAL; }
+    g_opt[id].store(value, std::memory_order_relaxed);
+    return X3D_OK;
+}
+
+extern "C" int x3d_get_option(const char* name, int* value) {
+    std::call_once(g_opt_once, opt_init);
+    const int id = opt_find(name);
+    if (id < 0 || value == nullptr) { x3d_set_error("x3d_get_option: unknown option '%s'", name ? name : "(null)"); return X3D_EINVAL; }
+    *value = g_opt[id].load(std::memory_order_relaxed);
+    return X3D_OK;
+}
+
+// back to the start-up values (defaults, or what the environment gave)
+extern "C" int x3d_reset_options(void) {
+    std::call_once(g_opt_once, opt_init);
+    opt_init();
+    return X3D_OK;
+}
+
+extern "C" int x3d_option_count(void) { return X3D_OPT_COUNT; }
+extern "C" const char* x3d_option_name(int index) { return (index >= 0 && index < X3D_OPT_COUNT) ? kOpts[index].name : nullptr; }

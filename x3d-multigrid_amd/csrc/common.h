@@ -9,6 +9,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void x3d_set_error(const char* fmt, ...);
 
+// Options of the library (api.hip; set with x3d_set_option, include/x3dhip.h).  x3d_opt(id) is the value NOW: entry
+// points and tile-count queries read it per call, never cache it.
+enum X3DOpt {
+    X3D_OPT_FB_GRID = 0,      // persistent grid of the fused stage 1-2 kernels (pwf.hip)                       512
+    X3D_OPT_PW_PGRID,         // grid cap of the persistent tiled pointwise kernels (pw4 / pw5)                   512
+    X3D_OPT_PW_NT4_MIN,       // streaming pointwise kernels: minimum workgroup count for the float4 form         256
+    X3D_OPT_PW_NO_PERSIST,    // non-persistent LDS-tiled pw2 instead of pw4 / pw5                                 0
+    X3D_OPT_DW_TH,            // channelwise kernels: maximum rows per tile                                        16
+    X3D_OPT_DW_BALANCE,       // channelwise kernels: equal tile heights                                           1
+    X3D_OPT_DW_NO_V2,         // channelwise kernels: element loads instead of float2 pairs on even widths         0
+    X3D_OPT_NO_PW6,           // chunked pw4 instead of the whole-K forward pw6                                    0
+    X3D_OPT_NO_PW7,           // chunked pw5 instead of the whole-K data gradient pw7                              0
+    X3D_OPT_NO_PWFS,          // streaming pw3 instead of the stage 1-2 forward pw_fwd_stream                      0
+    X3D_OPT_DGRAD_F32,        // exact fp32-MFMA data-gradient kernels                                             0
+    X3D_OPT_WGRAD_F32,        // exact fp32-MFMA weight-gradient kernels                                           0
+    X3D_OPT_BWD_TERMS,        // bf16 terms per fp32 operand in the backward GEMMs: 3 (fp32 level) or 2 (~2^-16)   3
+    X3D_OPT_NO_WGRAD4,        // 128 x 64 weight-gradient tiles instead of the wide ones                           0
+    X3D_OPT_WG_CPW,           // weight gradient: voxel chunks per workgroup                                       8
+    X3D_OPT_WG_CAP,           // weight gradient: workgroup cap per conv                                           256
+    X3D_OPT_STEM_WG_CAP,      // stem weight gradient: workgroups                                                  512
+    X3D_OPT_COUNT
+};
+int x3d_opt(int id);
+
 #define X3D_CHECK_ARG(cond)                                                       \
     do {                                                                          \
         if (!(cond)) {                                                            \

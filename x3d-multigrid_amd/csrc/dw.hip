@@ -41,8 +41,8 @@ static DwGeom make_geom(int N, int C, int T, int H, int W, int stride, bool back
     g.Wo = stride == 2 ? (W - 1) / 2 + 1 : W;
     const int GH = backward ? H : g.Ho, GW = backward ? W : g.Wo;   // thread grid
     g.groups = cdiv(GW, 4);
-    static const int th_max = getenv("X3D_DW_TH") ? atoi(getenv("X3D_DW_TH")) : DW_TH;
-    static const bool balance = getenv("X3D_DW_BALANCE") == nullptr || atoi(getenv("X3D_DW_BALANCE")) != 0;   // default on: +0.6 %
+    const int th_max = x3d_opt(X3D_OPT_DW_TH);
+    const bool balance = x3d_opt(X3D_OPT_DW_BALANCE) != 0;   // default on: +0.6 %
     int th = 256 / g.groups;
     if (th < 1) th = 1;
     if (th > th_max) th = th_max;
@@ -85,14 +85,30 @@ struct Chunk {
     float sc, sh;  // producer BN scale / shift of the chunk's channel
 };
 
+// Staged rows of one tile: rows row0 .. row0 + IH - 1 of a plane of SH rows; only those inside the plane are staged (the
+// others stay the zeros the ring was cleared to).  ONE definition for the kernels (make_chunks) and for the host's choice of
+// the per-thread chunk-slot count (nch_for): the two must agree, or `idx < total` would drop chunks silently.
+__host__ __device__ inline void dw_staged_rows(int IH, int row0, int SH, int* r_lo, int* nrows) {
+    const int lo = row0 < 0 ? -row0 : 0;
+    const int hi = IH < SH - row0 ? IH : SH - row0;
+    *r_lo = lo;
+    *nrows = hi > lo ? hi - lo : 0;
+}
+// first staged row of a tile: forward stages the INPUT rows of its output tile, backward the OUTPUT rows of its input tile
+__host__ __device__ inline int dw_tile_row0(int tile, int TH, int stride, bool backward) {
+    if (!backward) return tile * TH * stride - 1;
+    return stride == 1 ? tile * TH - 1 : (tile * TH) / 2 - 1;
+}
+
 template <int NCH>
 __device__ __forceinline__ void make_chunks(const DwGeom& g, int n, int c0, int row0, int SH, int SW,
                                             const float* pre, Chunk (&ch)[NCH]) {
-    // staged tensor: rows row0 .. row0+IH-1 of a [C][T][SH][SW] volume.  Only the rows that lie inside the tensor get a chunk
-    // (the others stay the zeros the ring was cleared to): a tile that covers the whole plane stages SH rows, not SH + 2 --
-    // which is what lets the 7 x 7 planes (16 channels x 9 rows x 2 chunks = 288) fit one chunk per thread.
+    // staged tensor: rows row0 .. row0+IH-1 of a [C][T][SH][SW] volume.  Only the rows that lie inside the tensor get a chunk:
+    // a tile that covers the whole plane stages SH rows, not SH + 2 -- which is what lets the 7 x 7 planes (16 channels x
+    // 9 rows x 2 chunks = 288) fit one chunk per thread.
     const int w4n = g.WP / 4 - 2;
-    const int r_lo = max(0, -row0), r_hi = min(g.IH, SH - row0), nrows = max(r_hi - r_lo, 0);
+    int r_lo, nrows;
+    dw_staged_rows(g.IH, row0, SH, &r_lo, &nrows);
     const int total = g.cpb * nrows * w4n;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, c0 = blockIdx.y * g.cpb, n = blockIdx.z;
     const int ho0 = tile * g.TH;
-    const int h_in0 = ho0 * STRIDE - 1;
+    const int h_in0 = dw_tile_row0(tile, g.TH, STRIDE, false);
     float* ring = lds;                                  // 2 slots
     float* redbuf = lds + 2 * (size_t)g.slot;           // 256*2 floats
 
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, c0 = blockIdx.y * g.cpb, n = blockIdx.z;
     const int h0 = tile * g.TH;                                   // first input row of the tile
-    const int ho_lo = STRIDE == 1 ? h0 - 1 : h0 / 2 - 1;          // first staged output row
+    const int ho_lo = dw_tile_row0(tile, g.TH, STRIDE, true);     // first staged output row
     float* ring = lds;
 
     for (int i = tid; i < 2 * g.slot; i += 256) ring[i] = 0.f;
@@ -847,7 +863,12 @@ static size_t bwd_lds_bytes(const DwGeom& g) {
 // chunk slots per thread: staged rows inside the tensor (see make_chunks) x float4 chunks per row x channels
 static int nch_for(const DwGeom& g, bool backward) {
     const int SH = backward ? g.Ho : g.H;
-    const int rows = g.tiles == 1 ? (g.IH < SH ? g.IH : SH) : g.IH;
+    int rows = 0;
+    for (int tile = 0; tile < g.tiles; ++tile) {       // the same row arithmetic as make_chunks, maximum over the tiles
+        int r_lo, nrows;
+        dw_staged_rows(g.IH, dw_tile_row0(tile, g.TH, g.stride, backward), SH, &r_lo, &nrows);
+        rows = nrows > rows ? nrows : rows;
+    }
     return cdiv(g.cpb * rows * (g.WP / 4 - 2), 256);
 }
 
@@ -898,7 +919,7 @@ static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, h
         const auto& ARGS_ = ARGS; const DwGeom& GEO_ = GEO; const size_t LDSB_ = LDSB;                 \
         const int nch = nch_for(GEO_, BWD_);                                                           \
         const bool uni = GEO_.cpb == 1;                                                                \
-        static const bool no_v2 = getenv("X3D_DW_NO_V2") != nullptr;                                   \
+        const bool no_v2 = x3d_opt(X3D_OPT_DW_NO_V2) != 0;                                             \
         const int vw = ((GEO_.W % 4 == 0) && (GEO_.Wo % 4 == 0)) ? 4                                   \
                      : (((GEO_.W % 2 == 0) && (GEO_.Wo % 2 == 0) && !no_v2) ? 2 : 1);                   \
         int rc_ = X3D_OK;                                                                              \

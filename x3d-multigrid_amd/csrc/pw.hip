@@ -1539,7 +1539,7 @@ __global__ __launch_bounds__(256, 2) void pw5_kernel(const PwArgs A) {
 // variant: 0 = streaming NT=4, 1 = streaming NT=1, 2 = LDS-tiled (pw2)
 static void pw_plan(int N, int K, int M, int P, bool dense, int* variant, int* tiles, int* mblocks, int* mt_run) {
     const int mtiles = cdiv(M, 16);
-    const bool no_persist = getenv("X3D_PW_NO_PERSIST") != nullptr;      // A/B knob (tests, tools/microbench.py); read per call
+    const bool no_persist = x3d_opt(X3D_OPT_PW_NO_PERSIST) != 0;         // A/B knob (tests, tools/microbench.py); read per call
     if (K >= 64 && M >= 96 && dense && (P % 4 == 0) && !no_persist) {
         // persistent pipelined kernel: units of (M tile, half voxel tile), U = ceil(mt_run / 2) per wave;
         // fewest M blocks (each restages the activation tile) unless one more block removes a whole unit row
@@ -1576,7 +1576,7 @@ static void pw_plan(int N, int K, int M, int P, bool dense, int* variant, int* t
         // small-P layers: 16 voxels per wave (NT = 1) gives 4x the waves -- but the float4 form moves the same bytes with
         // a quarter of the memory instructions and wins as soon as its workgroups cover the CUs (stage 2 at the base
         // shape: 392 / 784 workgroups, +1.4 % on the step), unless the last 256-voxel tile of a sample is mostly empty
-        static const long long nt4_min = getenv("X3D_PW_NT4_MIN") ? atoll(getenv("X3D_PW_NT4_MIN")) : 256;
+        const long long nt4_min = x3d_opt(X3D_OPT_PW_NT4_MIN);
         const bool full_tiles = (long long)P * 10 >= (long long)cdiv(P, 256) * 256 * 9;
         if (wgs < nt4_min || (wgs < 1024 && !full_tiles)) v = 1;
     }
@@ -1608,10 +1608,10 @@ int launch_pw(PwArgs& A, hipStream_t s) {
     }
     if (variant == 3 && A.wp != nullptr) {
         const int items = cdiv(A.tiles * A.N, 8) * 8 * A.mblocks;
-        static const int pg_max = getenv("X3D_PW_PGRID") ? atoi(getenv("X3D_PW_PGRID")) : 512;
+        const int pg_max = x3d_opt(X3D_OPT_PW_PGRID);
         dim3 pgrid(min(items, pg_max));         // two resident workgroups per CU walk the item list
         const int U = cdiv(A.mt_run, 2);
-        if (IN == IN_BNBWD && EPI != EPI_STATS && getenv("X3D_DGRAD_F32") == nullptr) {
+        if (IN == IN_BNBWD && EPI != EPI_STATS && !x3d_opt(X3D_OPT_DGRAD_F32)) {
             // backward-data: split-bf16 MFMA (the transposed pack carries the bf16 planes)
             constexpr int E5 = (EPI == EPI_STATS) ? EPI_PLAIN : EPI;
             if (U <= 2) hipLaunchKernelGGL((pw5_kernel<E5, 2>), pgrid, block, 0, s, A);
@@ -2371,7 +2371,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad3_batch_kernel(const WgBatch B
 }
 
 static bool wgrad2_ok(int P, long long Pin, int Co, int Ci, bool strided) {
-    if (strided) return (P % 4 == 0) && getenv("X3D_WGRAD_F32") == nullptr;    // gathered input: split-bf16 kernel only
+    if (strided) return (P % 4 == 0) && !x3d_opt(X3D_OPT_WGRAD_F32);           // gathered input: split-bf16 kernel only
     return (P % 4 == 0) && (Pin % 4 == 0);
 }
 // workgroup tile of the split-bf16 kernel for a Co x Ci weight
@@ -2379,7 +2379,7 @@ static int wg3_co(int Co) { return Co > 64 ? 128 : 64; }
 static int wg3_ci(int Ci) { return Ci > 32 ? 64 : 32; }
 // wide tiles (wgrad4_body, batched launches only): 1 = 256 x 96 (many dY channels), 2 = 128 x 224 (many input channels)
 static int wg4_kind(int Co, int Ci, bool dense) {
-    static const bool off = getenv("X3D_NO_WGRAD4") != nullptr;
+    const bool off = x3d_opt(X3D_OPT_NO_WGRAD4) != 0;
     if (off || !dense) return 0;
     if (Co > 128 && Ci > 64) return Co >= Ci ? 1 : 2;
     if (Co > 64 && Ci > 128) return 2;
@@ -2391,7 +2391,7 @@ static void wgrad_plan(int N, int P, int Co, int Ci, bool dense, int* tiled, int
                        int* ct_run, int* it_run) {
     if (wgrad2_ok(P, dense ? P : 1, Co, Ci, !dense)) {
         *tiled = 1;
-        const bool f32 = getenv("X3D_WGRAD_F32") != nullptr;     // exact fp32-MFMA kernel: fixed 128 x 64 tiles
+        const bool f32 = x3d_opt(X3D_OPT_WGRAD_F32) != 0;        // exact fp32-MFMA kernel: fixed 128 x 64 tiles
         *cob = cdiv(Co, f32 ? W2_CO : wg3_co(Co)); *cib = cdiv(Ci, f32 ? W2_CI : wg3_ci(Ci));
         *ct_run = 8; *it_run = 4;
         const int chunks = N * cdiv(P, W2_PT);
@@ -2399,8 +2399,8 @@ static void wgrad_plan(int N, int P, int Co, int Ci, bool dense, int* tiled, int
         // backward pass together (x3d_pw_bwd_weight_batch), so the chip is filled by the batch and fewer, longer
         // workgroups mean fewer partials to write and sum (measured 3/640 -> 8/256: +1 % on the step; for a conv
         // launched on its own 3/640 is the better choice)
-        static const int cpw = getenv("X3D_WG_CPW") ? atoi(getenv("X3D_WG_CPW")) : 8;
-        static const int wcap = getenv("X3D_WG_CAP") ? atoi(getenv("X3D_WG_CAP")) : 256;
+        const int cpw = x3d_opt(X3D_OPT_WG_CPW);
+        const int wcap = x3d_opt(X3D_OPT_WG_CAP);
         int g = cdiv(chunks, cpw);
         const int cap = wcap / ((*cob) * (*cib)) > 16 ? wcap / ((*cob) * (*cib)) : 16;
         if (g > cap) g = cap;
@@ -2670,14 +2670,14 @@ extern "C" int x3d_pw_bwd_weight(const void* g, const void* a, const float* cb, 
                &A.it_run);
     X3D_CHECK_ARG(A.cob * A.cib <= 65535);
     dim3 grid(A.groups, A.cob * A.cib), block(256);
-    if (mx && tiled && (A.strided || getenv("X3D_WGRAD_F32") != nullptr)) {
+    if (mx && tiled && (A.strided || x3d_opt(X3D_OPT_WGRAD_F32))) {
         x3d_set_error("pw_bwd_weight: no mixed-storage kernel for Cin=%d Cout=%d P=%d stride=%d", Cin, Cout, A.P, strideHW);
         return X3D_EINVAL;
     }
     if (tiled) {
         // split-bf16 MFMA (3 products, ~1e-5 on dW) by default; X3D_WGRAD_F32 selects the exact fp32-MFMA kernel
         hipStream_t s3 = (hipStream_t)stream;
-        if (getenv("X3D_WGRAD_F32") != nullptr) {
+        if (x3d_opt(X3D_OPT_WGRAD_F32)) {
             hipLaunchKernelGGL(pw_wgrad2_kernel, grid, block, 0, s3, A);
         } else if (A.strided) {
             if (wg3_co(Cout) == 128) {
@@ -2726,7 +2726,7 @@ extern "C" size_t x3d_wgrad_job_bytes(void) { return sizeof(X3DWgradJob); }
 extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void* stream) {
     X3D_CHECK_ARG(jobs && njobs > 0);
     hipStream_t s = (hipStream_t)stream;
-    const bool f32 = getenv("X3D_WGRAD_F32") != nullptr;
+    const bool f32 = x3d_opt(X3D_OPT_WGRAD_F32) != 0;
     // variant id: bit 0 = CI 64, bit 1 = CO 128, bit 2 = gathered (strided) input; -1 = not a wgrad3 shape
     // + 10: the mixed-storage builds of the same variants.  Their storage flags are per job, so when ANY job of the call
     // has a bf16 tensor the whole call runs on them -- one launch per tile variant either way (splitting the batch by

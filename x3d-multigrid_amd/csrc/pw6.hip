@@ -430,7 +430,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
 
 // shapes pw6 takes (the caller has checked: dense, packed weights present)
 bool x3d_pw6_ok(int K, int M, int P) {
-    static const bool off = getenv("X3D_NO_PW6") != nullptr;
+    const bool off = x3d_opt(X3D_OPT_NO_PW6) != 0;
     return !off && K >= 64 && K <= P6_RP * P6_MAXPASS && M >= 96 && (P % 4 == 0) && P >= 4;
 }
 
@@ -474,12 +474,12 @@ int x3d_pw6_launch(const void* x, const float* cin, const float* wp, void* y, fl
 
 // ---- data gradient (pw7_kernel): K = Cout, M = Cin
 bool x3d_pw7_ok(int K, int M, int P, int mx) {
-    static const bool off = getenv("X3D_NO_PW7") != nullptr;
+    const bool off = x3d_opt(X3D_OPT_NO_PW7) != 0;
     // measured at the base shape: K = 216 -> M = 96 (conv1 of stage 3) is the one layer where the chunked pw5_kernel is
     // not slower (23.6 vs 24.9 us: six of the eight waves own an M tile, seven k steps of staging for each)
     // (the mixed-storage mode has no chunked kernel: always here)
     if (!mx && K > 128 && K < 256 && M <= 96) return false;
-    return !off && getenv("X3D_DGRAD_F32") == nullptr && K >= 64 && K <= P6_RP * P6_MAXPASS && M >= 96 && (P % 4 == 0) && P >= 4;
+    return !off && !x3d_opt(X3D_OPT_DGRAD_F32) && K >= 64 && K <= P6_RP * P6_MAXPASS && M >= 96 && (P % 4 == 0) && P >= 4;
 }
 
 int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* wpt, void* out, float* partial, int mode,

@@ -664,7 +664,7 @@ extern "C" int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P, int mode, int has_a
 
 extern "C" int x3d_pw_bwd_fused_groups(int N, int P) {
     const long long chunks = (long long)N * ((P + F_PT - 1) / F_PT);
-    static const int gmax = getenv("X3D_FB_GRID") ? atoi(getenv("X3D_FB_GRID")) : 512;
+    const int gmax = x3d_opt(X3D_OPT_FB_GRID);
     return (int)(chunks < gmax ? chunks : gmax);
 }
 
@@ -732,7 +732,7 @@ extern "C" int x3d_pw_bwd_fused(const void* g, const void* a, const float* cb, c
 
 // ---- forward, stages 1-2 (pw_fwd_stream_kernel): dense, K, M <= 128, P % 4 == 0
 bool x3d_pwfs_ok(int K, int M, int P) {
-    static const bool off = getenv("X3D_NO_PWFS") != nullptr;
+    const bool off = x3d_opt(X3D_OPT_NO_PWFS) != 0;
     // measured at the base shape (gpurun_out/r2/launches{19,21}.json): the expanding convs (K = 24 / 48 -> M = 54 / 108: the
     // output stream dominates) gain 20-25 % over the fp32-MFMA streaming kernel pw3; the contracting ones (K = 54 / 108 ->
     // M = 24 / 48: Swish + 3-way split of a wide input, a third of the waves idle in the MFMA phase, 100 KB of LDS at

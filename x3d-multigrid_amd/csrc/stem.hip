@@ -351,7 +351,7 @@ extern "C" int x3d_stem133_fwd(const float* x, const float* w, float* y, int N, 
 }
 
 extern "C" int x3d_stem_wgrad_groups(int N, int T) {
-    static const int cap = getenv("X3D_STEM_WG_CAP") ? atoi(getenv("X3D_STEM_WG_CAP")) : 512;
+    const int cap = x3d_opt(X3D_OPT_STEM_WG_CAP);
     const int g = N * T * 8;
     return g < cap ? g : cap;
 }

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx3dhip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 
@@ -28,6 +28,11 @@ SIGNATURES = {
     "x3d_clip_job_bytes": (_Z, []),
     "x3d_clip_preprocess": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "x3d_last_error": (ctypes.c_char_p, []),
+    "x3d_set_option": (_I, [ctypes.c_char_p, _I]),
+    "x3d_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
+    "x3d_reset_options": (_I, []),
+    "x3d_option_count": (_I, []),
+    "x3d_option_name": (ctypes.c_char_p, [_I]),
     "x3d_pw_tiles": (_I, [_I, _I, _I, _I, _I]),
     "x3d_pw_fwd_tiles": (_I, [_I, _I, _I, _I, _I, _I]),
     "x3d_pw_bwd_tiles": (_I, [_I, _I, _I, _I, _I, _I]),
@@ -114,6 +119,41 @@ def lib():
         raise X3DHipError("libx3dhip.so ABI %d != expected %d" % (v, ABI_VERSION))
     _lib = h
     return h
+
+
+def set_option(name, value):
+    """Library option `name` := value (include/x3dhip.h x3d_set_option); returns the previous value."""
+    prev = get_option(name)
+    check(lib().x3d_set_option(name.encode(), int(value)))
+    return prev
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(lib().x3d_get_option(name.encode(), ctypes.byref(v)))
+    return v.value
+
+
+def option_names():
+    L = lib()
+    return [L.x3d_option_name(i).decode() for i in range(L.x3d_option_count())]
+
+
+class options:
+    """Context manager: `with _lib.options(fb_grid=8, dgrad_f32=1): ...` -- options restored on exit."""
+
+    def __init__(self, **kw):
+        self.kw, self.prev = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.prev[k] = set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        return False
 
 
 def check(rc):

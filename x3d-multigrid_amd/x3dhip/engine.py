@@ -21,7 +21,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH
 
 BN_EPS = 1e-5        # nn.BatchNorm3d defaults used by SubBatchNorm3d (x3d.py:23-25)
@@ -76,6 +76,8 @@ class WeightPacks:
                 items.append(int(L.x3d_pw_pack_items(K, M, 1 if transposed else 0)))
                 metas.append((w, transposed, M, K, 1 if transposed else ci, ci if transposed else 1))
         self.buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        if ops.poisoned():
+            self.buf.fill_(float("nan"))
         jobs = np.zeros(len(metas), dtype=dt)
         wg_job, off, wg = [], 0, 0
         self.views, self.ptrs = {}, []
@@ -122,23 +124,35 @@ class TrunkContext:
         self.head = None
 
 
-_NO_DW_STATS = os.environ.get("X3D_NO_DW_STATS", "0") == "1"
-_DW_BWD_STATS = os.environ.get("X3D_DW_BWD_STATS", "1") == "1"
-_NO_RES_FUSE = os.environ.get("X3D_NO_RES_FUSE", "0") == "1"
-_NO_BATCH_REDUCE = os.environ.get("X3D_NO_BATCH_REDUCE", "0") == "1"
-_NO_FUSED_BWD = os.environ.get("X3D_NO_FUSED_BWD", "0") == "1"
-# X3D_WGRAD_OVERLAP=1: the postponed weight gradients of layer4 / layer3 are launched on a second stream when their stage's
-# data-gradient chain is done, beside the NEXT stage's chain.  OFF by default: measured 8.89 vs 8.59 ms per step in round 2
-# (two forks per replay; co-running kernels slow the latency-bound chain by more than the overlap hides -- the same
-# result as round 1's per-conv side stream)
-_WGRAD_OVERLAP = os.environ.get("X3D_WGRAD_OVERLAP", "0") == "1"
+class _Config:
+    """Host-side A/B switches of the schedule.  Attributes, read at call time: a test flips one
+    in-process (`engine.cfg.no_fused_bwd = True`); each starts from the environment variable of the same meaning.  The
+    switches that select between KERNELS live in the library (x3dhip._lib.set_option / include/x3dhip.h x3d_set_option)."""
+
+    def __init__(self):
+        env = os.environ.get
+        self.no_dw_stats = env("X3D_NO_DW_STATS", "0") == "1"        # separate BN1 finalize launch
+        self.dw_bwd_stats = env("X3D_DW_BWD_STATS", "1") == "1"      # BN2-backward finalize in the depthwise prologue
+        self.no_res_fuse = env("X3D_NO_RES_FUSE", "0") == "1"        # separate bn_add_relu_bwd launch
+        self.no_batch_reduce = env("X3D_NO_BATCH_REDUCE", "0") == "1"
+        self.no_fused_bwd = env("X3D_NO_FUSED_BWD", "0") == "1"      # stages 1-2: separate dgrad + batched wgrad
+        # X3D_WGRAD_OVERLAP=1: the postponed weight gradients of layer4 / layer3 are launched on a second stream when their
+        # stage's data-gradient chain is done, beside the NEXT stage's chain.  OFF by default: measured 8.89 vs 8.59 ms per
+        # step in round 2 (two forks per replay; co-running kernels slow the latency-bound chain by more than the overlap
+        # hides -- the same result as round 1's per-conv side stream)
+        self.wgrad_overlap = env("X3D_WGRAD_OVERLAP", "0") == "1"
+        self.side_stream = env("X3D_SIDE_STREAM") == "1" and env("X3D_NO_SIDE_STREAM") != "1"
+        self.exp_skip_wgrad = env("X3D_EXP_SKIP_WGRAD") == "1"       # timing experiment only: gradients are wrong
+
+
+cfg = _Config()
 
 
 def _fused_bwd(grads, g, x, mode=0, has_addend=False):
     """Stages 1-2: data gradient and weight gradient of a pointwise conv from one pass (ops.pw_bwd_fused)."""
-    if _NO_FUSED_BWD or grads.side is not None or os.environ.get("X3D_EXP_SKIP_WGRAD") == "1":
+    if cfg.no_fused_bwd or grads.side is not None or cfg.exp_skip_wgrad:
         return False
-    if os.environ.get("X3D_DGRAD_F32") or os.environ.get("X3D_WGRAD_F32"):      # exact-fp32 A/B switches: separate kernels
+    if _lib.get_option("dgrad_f32") or _lib.get_option("wgrad_f32"):      # exact-fp32 A/B switches: separate kernels
         return False
     if tuple(x.shape[2:]) != tuple(g.shape[2:]):
         return False
@@ -215,7 +229,7 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx, packs, wide=torch.float
     a1, p1 = ops.pw_fwd(x_raw, w1, pre=x_coef, pre_act=pre_act, want_stats=training, wp=packs.get(blk.conv1.weight),
                         out_dtype=wide)
     P1 = a1[0, 0].numel()
-    if training and not _NO_DW_STATS:
+    if training and not cfg.no_dw_stats:
         # bn1's finalize runs inside the depthwise kernel's prologue (one launch less per block)
         a2, p2, c1, s1 = ops.dw333_fwd_stats(a1, blk.conv2.weight.data, p1, S, P1, blk.bn1.weight.data, blk.bn1.bias.data,
                                              blk.bn1.split_bn.running_mean, blk.bn1.split_bn.running_var,
@@ -287,7 +301,7 @@ class _GradSink:
         self.written = {}
         self.side = side          # HIP stream for the weight-gradient kernels (off the critical path)
         # group sums of the weight-gradient partials, postponed to one launch per backward part (single-stream mode)
-        self.deferred = ops.DeferredGrads() if (side is None and not _NO_BATCH_REDUCE) else None
+        self.deferred = ops.DeferredGrads() if (side is None and not cfg.no_batch_reduce) else None
 
     def flush(self):
         if self.deferred is not None:
@@ -298,7 +312,7 @@ class _GradSink:
         """Launch what has been postponed so far on the second stream (fork here, join in flush()).  Every tensor the
         launches read or write stays referenced until the join."""
         d = self.deferred
-        if d is None or not _WGRAD_OVERLAP or self.side is not None or (not d.wjobs and not d.reduces):
+        if d is None or not cfg.wgrad_overlap or self.side is not None or (not d.wjobs and not d.reduces):
             return
         main = torch.cuda.current_stream()
         st = side_stream(device)
@@ -400,7 +414,7 @@ def use_side_stream():
     since the persistent dgrad / split-bf16 wgrad kernels the forked graph replays 3.8 % slower than the linear one
     (10.85 vs 10.46 ms at config 2: the overlapped kernels slow each other down by about what the overlap hides, and
     every fork / join is a cross-queue dependency).  X3D_SIDE_STREAM=1 turns it back on."""
-    return os.environ.get("X3D_SIDE_STREAM") == "1" and os.environ.get("X3D_NO_SIDE_STREAM") != "1"
+    return cfg.side_stream
 
 
 def side_stream(device):
@@ -416,7 +430,7 @@ def _wgrad(grads, w, g, a, cb, x, **kw):
     """Pointwise weight gradient.  Nothing downstream in the backward pass consumes it, so it runs
     on the side stream, concurrently with the data-gradient chain (the small stage-3/4 kernels
     cannot fill 256 CUs on their own); joined once at the end of trunk_backward."""
-    if os.environ.get("X3D_EXP_SKIP_WGRAD") == "1":      # timing experiment only: gradients are wrong
+    if cfg.exp_skip_wgrad:      # timing experiment only: gradients are wrong
         o = grads.out(w)
         grads.put(w, o if o is not None else torch.zeros_like(w))
         return
@@ -452,7 +466,7 @@ def _on_side(grads, fn, tensors):
 def _res_fusable(rec):
     """The residual-add + ReLU backward of this block can ride in the epilogue of the data gradient that produces its
     output gradient (no downsample branch: one statistics pair)."""
-    return rec is not None and rec["ad"] is None and not _NO_RES_FUSE
+    return rec is not None and rec["ad"] is None and not cfg.no_res_fuse
 
 
 def _block_backward(rec, dout, grads, below=None):
@@ -496,7 +510,7 @@ def _block_backward(rec, dout, grads, below=None):
         grads.put(blk.fc1.bias, o["db1"])
         grads.put(blk.fc2.weight, o["dw2"])
         grads.put(blk.fc2.bias, o["db2"])
-    elif S == 1 and _DW_BWD_STATS:
+    elif S == 1 and cfg.dw_bwd_stats:
         cb2 = None          # bn2's backward finalize runs in the depthwise kernel's prologue
     else:
         cb2 = _bn_bwd(grads, ps, S, P2, blk.bn2, rec["s2"])
@@ -506,7 +520,7 @@ def _block_backward(rec, dout, grads, below=None):
     if cb2 is None:
         dg2, db2 = grads.out(blk.bn2.weight), grads.out(blk.bn2.bias)
         if dg2 is None:
-            dg2, db2 = torch.empty_like(blk.bn2.weight.data), torch.empty_like(blk.bn2.bias.data)
+            dg2, db2 = ops._f(blk.bn2.weight.shape, blk.bn2.weight.data), ops._f(blk.bn2.bias.shape, blk.bn2.bias.data)
         bn2 = (ps, P2, blk.bn2.weight.data, rec["s2"], dg2, db2)
         grads.put(blk.bn2.weight, dg2)
         grads.put(blk.bn2.bias, db2)

@@ -5,6 +5,7 @@ with torch, passes raw pointers to libx3dhip.so on the current HIP stream and re
 tensors.  There is no fallback: a missing library or a CPU tensor raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -53,8 +54,29 @@ def out_hw(h, stride):
     return (h - 1) // 2 + 1 if stride == 2 else h
 
 
+# Poison mode (debug / tests): every buffer this module allocates is filled with NaN before the kernel that owns it
+# runs, so a slot a kernel is supposed to write but skips -- statistics partials, weight-gradient partials, pack pads --
+# surfaces as a NaN in a named tensor instead of as whatever the caching allocator left there.  Read at call time
+# (`set_poison`, or X3D_POISON=1 in the environment at import); off by default: the product path never pays the fills.
+_poison = os.environ.get("X3D_POISON", "0") == "1"
+
+
+def set_poison(on):
+    """Turn NaN-filling of every freshly allocated buffer on / off; returns the previous setting."""
+    global _poison
+    prev, _poison = _poison, bool(on)
+    return prev
+
+
+def poisoned():
+    return _poison
+
+
 def _f(shape, like, dtype=torch.float32):
-    return torch.empty(shape, dtype=dtype, device=like.device)
+    t = torch.empty(shape, dtype=dtype, device=like.device)
+    if _poison:
+        t.fill_(float("nan"))
+    return t
 
 
 _scratch = {}
@@ -70,6 +92,8 @@ def scratch(dev, nbytes):
         if cur is not None:
             _scratch_retired.append(cur)
         cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        if _poison:
+            cur.fill_(0xFF)              # all-ones bytes read back as NaN in fp32 and fp64
         _scratch[dev] = cur
     return cur
 
