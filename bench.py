@@ -288,14 +288,17 @@ def main():
     value = world * B * args.steps / dt
 
     # the same step with the exact fp32-MFMA backward GEMMs (the switches are read per launch): reported beside the default
-    exact = None
+    exact = two_term = None
+    from x3dhip import _lib, engine
     if not args.no_exact_fp32 and not mixed:          # the exact fp32-MFMA backward kernels read fp32 tensors only
-        os.environ["X3D_DGRAD_F32"] = "1"
-        os.environ["X3D_WGRAD_F32"] = "1"
-        tr.invalidate_graphs()
-        dt_e, _ = timed_run()
+        with _lib.options(dgrad_f32=1, wgrad_f32=1):  # library options are read per launch; the captured graphs are re-captured
+            tr.invalidate_graphs()
+            dt_e, _ = timed_run()
         exact = (world * B * args.steps / dt_e, 1000.0 * dt_e / args.steps)
-        del os.environ["X3D_DGRAD_F32"], os.environ["X3D_WGRAD_F32"]
+        with _lib.options(bwd_terms=2):               # round 2's default: two-term operands in the backward GEMMs (~2^-16)
+            tr.invalidate_graphs()
+            dt_e, _ = timed_run()
+        two_term = (world * B * args.steps / dt_e, 1000.0 * dt_e / args.steps)
         tr.invalidate_graphs()
 
     E, Ew = algorithmic_elems_M(T, H, args.model, split=True)
@@ -306,14 +309,15 @@ def main():
         "metric": "clips/sec X3D-%s fwd+bwd+SGD at multigrid base shape (whole job)" % args.model,
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        # storage, stencils, BN and the optimizer are fp32.  Pointwise GEMMs run on the bf16 MFMA with fp32 operands split into
-        # bf16 terms, fp32 accumulate: forward 3 terms / 6 products (all 24 significant bits: fp32-level accuracy; the
-        # contracting stage 1-2 convs still use the fp32 MFMA), backward 2 terms / 3 products (~2^-16 per product) --
-        # value_exact_fp32 is the same job with the exact fp32-MFMA backward kernels
+        # storage, stencils, BN and the optimizer are fp32.  Pointwise GEMMs run on the bf16 MFMA with every fp32 operand split
+        # into THREE bf16 terms (hi + mid + lo = all 24 significant bits; six MFMA products, fp32 accumulate: fp32-level
+        # accuracy, forward AND backward; the contracting stage 1-2 forward convs and a few small layers use the fp32 MFMA
+        # directly).  value_exact_fp32 is the same job with the fp32-MFMA backward kernels, value_two_term_backward with
+        # round 2's two-term backward operands (~2^-16 per product).
         "dtype": ("bf16 storage of the wide bottleneck tensors (conv1 / conv2 outputs and their gradients), every other tensor "
                   "and all arithmetic f32 (pointwise GEMMs as in the f32 mode)" if mixed else
-                  "f32 (pointwise GEMMs: fp32 operands split into bf16 terms on the MFMA, fp32 accumulate; fwd 3-term = "
-                  "fp32-level, bwd 2-term ~2^-16)"), "data": "synthetic",
+                  "f32 (pointwise GEMMs on the MFMA with fp32 operands as 3 bf16 terms, fp32 accumulate: fp32-level, fwd and bwd)"),
+        "data": "synthetic",
         "config": {"workload": "X3D-%s train step B=%d/GPU T=%d H=W=%d, 400 classes, dropout 0.5, SGD momentum" % (args.model, B, T, H),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "storage": "bf16 wide tensors / f32" if mixed else "f32",
@@ -321,9 +325,9 @@ def main():
                    # storage, forward GEMMs, stencils, BN: fp32.  Backward pointwise GEMMs: fp32 operands split into
                    # hi+lo bf16 (3 MFMA products, fp32 accumulate, ~2^-16 per product; parity-verified)
                    # unless X3D_DGRAD_F32 / X3D_WGRAD_F32 select the exact fp32-MFMA kernels
-                   "backward_gemm": ("fp32 MFMA" if os.environ.get("X3D_DGRAD_F32") else "split-bf16x3 dgrad") + " / " +
-                                    ("fp32 MFMA" if os.environ.get("X3D_WGRAD_F32") else "split-bf16x3 wgrad") +
-                                    ("" if (os.environ.get("X3D_DGRAD_F32") or os.environ.get("X3D_NO_FUSED_BWD") == "1")
+                   "backward_gemm": ("fp32 MFMA" if _lib.get_option("dgrad_f32") else "%d-term bf16 dgrad" % _lib.get_option("bwd_terms")) + " / " +
+                                    ("fp32 MFMA" if _lib.get_option("wgrad_f32") else "%d-term bf16 wgrad" % _lib.get_option("bwd_terms")) +
+                                    ("" if (_lib.get_option("dgrad_f32") or engine.cfg.no_fused_bwd)
                                      else " (stages 1-2: one fused dgrad+wgrad pass)"),
                    "loss": round(float(loss), 4)},
         "step_hbm_roofline": {"algorithmic_bytes_per_step": step_bytes,
@@ -334,12 +338,14 @@ def main():
     if exact is not None:
         out["value_exact_fp32"] = round(exact[0], 2)
         out["ms_per_step_exact_fp32"] = round(exact[1], 3)
+        out["value_two_term_backward"] = round(two_term[0], 2)
+        out["ms_per_step_two_term_backward"] = round(two_term[1], 3)
     if not args.no_kernel_timing:
         # one instrumented eager step: HIP events around every launch, same tensors.  EVERY rank runs these steps (they
         # contain the gradient all-reduce: the collectives must match across ranks); only rank 0 records and reports.
         tr_e = tr
         tr_e.use_graph = False
-        os.environ["X3D_NO_SIDE_STREAM"] = "1"      # serialise the weight-gradient kernels: clean per-kernel times
+        engine.cfg.side_stream = False              # serialise the weight-gradient kernels: clean per-kernel times
         for _ in range(2):          # eager warm-up: allocator + code objects outside the graph pool
             tr_e.step(x, y)
         torch.cuda.synchronize()

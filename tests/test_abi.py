@@ -38,6 +38,30 @@ def test_library_loads_and_exports_every_symbol():
     assert h.x3d_last_error() is not None
 
 
+def test_option_table_set_get_reset():
+    """x3d_set_option / x3d_get_option / x3d_reset_options (host only): every declared name round-trips, values are range
+    checked, unknown names fail, and tile-count queries follow an option at call time."""
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    names = _lib.option_names()
+    assert {"fb_grid", "bwd_terms", "dgrad_f32", "wgrad_f32", "dw_th", "no_pw6", "no_pw7", "no_pwfs"} <= set(names)
+    assert _lib.get_option("bwd_terms") == 3 and _lib.get_option("fb_grid") == 512
+    h = _lib.lib()
+    assert h.x3d_pw_bwd_fused_groups(2, 24964) == 512
+    with _lib.options(fb_grid=7, bwd_terms=2):
+        assert _lib.get_option("fb_grid") == 7 and _lib.get_option("bwd_terms") == 2
+        assert h.x3d_pw_bwd_fused_groups(2, 24964) == 7
+    assert _lib.get_option("fb_grid") == 512 and _lib.get_option("bwd_terms") == 3
+    for bad in (("bwd_terms", 4), ("fb_grid", 0), ("dw_th", 17), ("dgrad_f32", 2)):
+        with pytest.raises(_lib.X3DHipError):
+            _lib.set_option(*bad)
+    with pytest.raises(_lib.X3DHipError):
+        _lib.set_option("no_such_option", 1)
+    _lib.set_option("dw_th", 8)
+    assert h.x3d_reset_options() == 0 and _lib.get_option("dw_th") == 16
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

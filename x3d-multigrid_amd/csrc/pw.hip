@@ -597,8 +597,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 // Packed weight image.
 //   fp32 part (always):   wp[((mt * kgroups + s) * 64 + lane) * 4 + e] = A[16 mt + (lane & 15)][16 s + 4 (lane >> 4) + e]
-//   split-bf16 part (transposed / backward-data packs only), directly behind the fp32 part, for the
-//   16x16x32 bf16 MFMA: two planes (hi = bf16(a), lo = bf16(a - hi)) of
+//   split-bf16 part, directly behind the fp32 part, for the 16x16x32 bf16 MFMA: three planes
+//   (hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid): all 24 significant bits; a two-term kernel reads hi, mid) of
 //                         wq[((mt * kg32 + s) * 64 + lane) * 8 + j] = A[16 mt + (lane & 15)][32 s + 8 (lane >> 4) + j]
 // One work item per fp32 element, then one per bf16 (hi, lo) pair.
 __device__ __forceinline__ void pack_item(int i, const float* __restrict__ w, float* __restrict__ wp, int M, int K, int ldm,
@@ -623,12 +623,12 @@ __device__ __forceinline__ void pack_item(int i, const float* __restrict__ w, fl
     const __bf16 h = (__bf16)v;
     __bf16* wq = reinterpret_cast<__bf16*>(wp + nf);
     wq[t] = h;
-    if (with_bf16 == 3) {           // forward packs: three planes hi + mid + lo = all 24 significant bits (pw6_kernel)
+    if (with_bf16 == 3) {           // three planes hi + mid + lo = all 24 significant bits (pw6 / pw7 / pwf / wgrad kernels)
         const float r1 = v - (float)h;
         const __bf16 m = (__bf16)r1;
         wq[nq + t] = m;
         wq[2 * nq + t] = (__bf16)(r1 - (float)m);
-    } else {                        // transposed packs: hi + lo (16 bits) for the backward kernels
+    } else {                        // two planes (unused since ABI 6; kept for x3d_pw_pack_batch jobs that ask for it)
         wq[nq + t] = (__bf16)(v - (float)h);
     }
 }
@@ -1611,8 +1611,10 @@ int launch_pw(PwArgs& A, hipStream_t s) {
         const int pg_max = x3d_opt(X3D_OPT_PW_PGRID);
         dim3 pgrid(min(items, pg_max));         // two resident workgroups per CU walk the item list
         const int U = cdiv(A.mt_run, 2);
-        if (IN == IN_BNBWD && EPI != EPI_STATS && !x3d_opt(X3D_OPT_DGRAD_F32)) {
-            // backward-data: split-bf16 MFMA (the transposed pack carries the bf16 planes)
+        if (IN == IN_BNBWD && EPI != EPI_STATS && !x3d_opt(X3D_OPT_DGRAD_F32) && x3d_opt(X3D_OPT_BWD_TERMS) == 2) {
+            // backward-data, two-term mode only: split-bf16 MFMA, hi + lo (the transposed pack carries the bf16 planes).  With
+            // three-term operands (the default) the shapes that reach this point -- K beyond pw7's LDS tile: X3D-XL's 630
+            // channels -- run on the exact fp32-MFMA pw4 below
             constexpr int E5 = (EPI == EPI_STATS) ? EPI_PLAIN : EPI;
             if (U <= 2) hipLaunchKernelGGL((pw5_kernel<E5, 2>), pgrid, block, 0, s, A);
             else if (U == 3) hipLaunchKernelGGL((pw5_kernel<E5, 3>), pgrid, block, 0, s, A);
@@ -2016,12 +2018,17 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad2_kernel(const WgArgs A) {
 // ---------------------------------------------------------------------------------------
 constexpr int W3_LD = 72;          // bf16 elements per LDS row
 
-__device__ __forceinline__ void split_bf16x4(const float (&v)[4], bf16x4& hi, bf16x4& lo) {
+// v = hi + mid + lo: three bf16 terms = all 24 significant bits of an fp32 value (mid = bf16(v - hi), lo = bf16(v - hi - mid));
+// the two-term kernels (NS = 2, option bwd_terms = 2) keep hi and mid
+__device__ __forceinline__ void split_bf16x4(const float (&v)[4], bf16x4& hi, bf16x4& mid, bf16x4& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const __bf16 h = (__bf16)v[e];
+        const float r1 = v[e] - (float)h;
+        const __bf16 m = (__bf16)r1;
         hi[e] = h;
-        lo[e] = (__bf16)(v[e] - (float)h);
+        mid[e] = m;
+        lo[e] = (__bf16)(r1 - (float)m);
     }
 }
 
@@ -2029,15 +2036,18 @@ __device__ __forceinline__ void split_bf16x4(const float (&v)[4], bf16x4& hi, bf
 // 32-column variants for the narrow ones (stages 1-2) so that padding rows are not staged for nothing.
 // GATHER: the input of a stride-(1,2,2) convolution (the downsample branch): its four voxels per slot are read at
 // (t, 2 ho, 2 wo) of the full-resolution input instead of as one float4.
-template <int CO, int CI, bool GATHER, bool MX>
+// NS: bf16 terms per fp32 operand: 3 = six MFMA products, fp32-level (default); 2 = three products, ~2^-16 per product.
+template <int CO, int CI, bool GATHER, bool MX, int NS>
 __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, const int blk) {
     const int ga_bf = MX ? A.ga_bf : 0, x_bf = (MX && !GATHER) ? A.x_bf : 0;
     constexpr int ND = CO / 16, NX = CI / 16;            // staged float4 slots per thread (dY, input)
     constexpr int MW = CO / 64, NW = CI / 16;            // 16x16 tiles per wave: MW (dY) x NW (input)
     __shared__ __attribute__((aligned(16))) __bf16 Dh[CO * W3_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Dlo[CO * W3_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Dm[CO * W3_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Dlo[(NS == 3 ? CO : 1) * W3_LD];
     __shared__ __attribute__((aligned(16))) __bf16 Xh[CI * W3_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Xlo[CI * W3_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Xm[CI * W3_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Xlo[(NS == 3 ? CI : 1) * W3_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, r = lane & 15;
@@ -2100,10 +2110,11 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
-            bf16x4 hi, lo;
-            split_bf16x4(v, hi, lo);
+            bf16x4 hi, mid, lo;
+            split_bf16x4(v, hi, mid, lo);
             *reinterpret_cast<bf16x4*>(&Dh[(row0 + 16 * i) * W3_LD + c4]) = hi;
-            *reinterpret_cast<bf16x4*>(&Dlo[(row0 + 16 * i) * W3_LD + c4]) = lo;
+            *reinterpret_cast<bf16x4*>(&Dm[(row0 + 16 * i) * W3_LD + c4]) = mid;
+            if (NS == 3) *reinterpret_cast<bf16x4*>(&Dlo[(row0 + 16 * i) * W3_LD + c4]) = lo;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -2116,10 +2127,11 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-            bf16x4 hi, lo;
-            split_bf16x4(v, hi, lo);
+            bf16x4 hi, mid, lo;
+            split_bf16x4(v, hi, mid, lo);
             *reinterpret_cast<bf16x4*>(&Xh[(row0 + 16 * i) * W3_LD + c4]) = hi;
-            *reinterpret_cast<bf16x4*>(&Xlo[(row0 + 16 * i) * W3_LD + c4]) = lo;
+            *reinterpret_cast<bf16x4*>(&Xm[(row0 + 16 * i) * W3_LD + c4]) = mid;
+            if (NS == 3) *reinterpret_cast<bf16x4*>(&Xlo[(row0 + 16 * i) * W3_LD + c4]) = lo;
         }
     };
 
@@ -2133,27 +2145,33 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
     auto compute = [&]() {
 #pragma unroll
         for (int s = 0; s < W2_PT / 32; ++s) {
-            bf16x8 ah[MW], al[MW], bh[NW], bl[NW];
+            bf16x8 ah[MW], am[MW], al[MW];
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
                 const int off = ((MW * wave + i) * 16 + r) * W3_LD + s * 32 + 8 * q;
                 ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
-                al[i] = *reinterpret_cast<const bf16x8*>(&Dlo[off]);
+                am[i] = *reinterpret_cast<const bf16x8*>(&Dm[off]);
+                if (NS == 3) al[i] = *reinterpret_cast<const bf16x8*>(&Dlo[off]);
             }
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const int off = (j * 16 + r) * W3_LD + s * 32 + 8 * q;
-                bh[j] = *reinterpret_cast<const bf16x8*>(&Xh[off]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
-            }
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Xh[off]);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Xm[off]);
+                bf16x8 bl;
+                if (NS == 3) bl = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
 #pragma unroll
-            for (int i = 0; i < MW; ++i)
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MW; ++i) {
+                    if (NS == 3) {                     // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
                 }
+            }
         }
     };
 
@@ -2189,7 +2207,7 @@ __device__ __forceinline__ void wgrad3_body(const WgArgs& A, const int grp, cons
 // instead of once per 128 x 64 block (4 blocks at stage 3, 12 at stage 4: the batched launches fetched 2.2x their
 // algorithmic bytes, profiles/r02/a_traffic.json, and split the same values four times).  Waves form a 4 (dY) x 2 (input)
 // grid: MW x NW sixteen-row tiles per wave keep the LDS fragment reads per MFMA at the 128 x 64 kernel's level.
-template <int CO, int CI, bool MX>
+template <int CO, int CI, bool MX, int NS>
 __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, const int blk) {
     const int ga_bf = MX ? A.ga_bf : 0, x_bf = MX ? A.x_bf : 0;
     constexpr int NT = 512, RP = NT / 16;                // 32 rows staged per pass
@@ -2198,10 +2216,12 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
     constexpr int MW = CO / 16 / WCO, NW = CI / 16 / WCI;
     static_assert(CO % (16 * WCO) == 0 && CI % (16 * WCI) == 0 && CO % RP == 0 && CI % RP == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) __bf16 wl4[];
-    __bf16* Dh = wl4;
-    __bf16* Dlo = Dh + CO * W3_LD;
-    __bf16* Xh = Dlo + CO * W3_LD;
-    __bf16* Xlo = Xh + CI * W3_LD;
+    __bf16* Dh = wl4;                                     // NS planes of dY, then NS planes of the input
+    __bf16* Dm = Dh + CO * W3_LD;
+    __bf16* Dlo = Dh + (NS - 1) * CO * W3_LD;
+    __bf16* Xh = Dh + NS * CO * W3_LD;
+    __bf16* Xm = Xh + CI * W3_LD;
+    __bf16* Xlo = Xh + (NS - 1) * CI * W3_LD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, r = lane & 15;
@@ -2251,10 +2271,11 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
-            bf16x4 hi, lo;
-            split_bf16x4(v, hi, lo);
+            bf16x4 hi, mid, lo;
+            split_bf16x4(v, hi, mid, lo);
             *reinterpret_cast<bf16x4*>(&Dh[(row0 + RP * i) * W3_LD + c4]) = hi;
-            *reinterpret_cast<bf16x4*>(&Dlo[(row0 + RP * i) * W3_LD + c4]) = lo;
+            *reinterpret_cast<bf16x4*>(&Dm[(row0 + RP * i) * W3_LD + c4]) = mid;
+            if (NS == 3) *reinterpret_cast<bf16x4*>(&Dlo[(row0 + RP * i) * W3_LD + c4]) = lo;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -2267,10 +2288,11 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-            bf16x4 hi, lo;
-            split_bf16x4(v, hi, lo);
+            bf16x4 hi, mid, lo;
+            split_bf16x4(v, hi, mid, lo);
             *reinterpret_cast<bf16x4*>(&Xh[(row0 + RP * i) * W3_LD + c4]) = hi;
-            *reinterpret_cast<bf16x4*>(&Xlo[(row0 + RP * i) * W3_LD + c4]) = lo;
+            *reinterpret_cast<bf16x4*>(&Xm[(row0 + RP * i) * W3_LD + c4]) = mid;
+            if (NS == 3) *reinterpret_cast<bf16x4*>(&Xlo[(row0 + RP * i) * W3_LD + c4]) = lo;
         }
     };
 
@@ -2284,22 +2306,30 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
     auto compute = [&]() {
 #pragma unroll
         for (int s = 0; s < W2_PT / 32; ++s) {
-            bf16x8 ah[MW], al[MW];
+            bf16x8 ah[MW], am[MW], al[MW];
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
                 const int off = ((wco0 + i) * 16 + r) * W3_LD + s * 32 + 8 * q;
                 ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
-                al[i] = *reinterpret_cast<const bf16x8*>(&Dlo[off]);
+                am[i] = *reinterpret_cast<const bf16x8*>(&Dm[off]);
+                if (NS == 3) al[i] = *reinterpret_cast<const bf16x8*>(&Dlo[off]);
             }
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const int off = ((wci0 + j) * 16 + r) * W3_LD + s * 32 + 8 * q;
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Xh[off]);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Xm[off]);
+                bf16x8 bl;
+                if (NS == 3) bl = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
 #pragma unroll
                 for (int i = 0; i < MW; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    if (NS == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
                 }
             }
@@ -2332,12 +2362,12 @@ __device__ __forceinline__ void wgrad4_body(const WgArgs& A, const int grp, cons
 }
 
 struct WgBatch;
-template <int CO, int CI, bool MX>
+template <int CO, int CI, bool MX, int NS>
 __global__ __launch_bounds__(512, 2) void pw_wgrad4_batch_kernel(const WgBatch B);
 
-template <int CO, int CI, bool GATHER, bool MX>
+template <int CO, int CI, bool GATHER, bool MX, int NS>
 __global__ __launch_bounds__(256, 2) void pw_wgrad3_kernel(const WgArgs A) {
-    wgrad3_body<CO, CI, GATHER, MX>(A, blockIdx.x, blockIdx.y);
+    wgrad3_body<CO, CI, GATHER, MX, NS>(A, blockIdx.x, blockIdx.y);
 }
 
 // Every weight gradient of a backward pass that uses the same tile variant in one launch (up to WB_MAX jobs, passed by
@@ -2352,22 +2382,22 @@ struct WgBatch {
     int njobs;
 };
 
-template <int CO, int CI, bool MX>
+template <int CO, int CI, bool MX, int NS>
 __global__ __launch_bounds__(512, 2) void pw_wgrad4_batch_kernel(const WgBatch B) {
     int j = 0;
     while (j + 1 < B.njobs && (int)blockIdx.x >= B.wg0[j + 1]) ++j;
     const int local = (int)blockIdx.x - B.wg0[j];
     const int groups = B.job[j].groups;
-    wgrad4_body<CO, CI, MX>(B.job[j], local % groups, local / groups);
+    wgrad4_body<CO, CI, MX, NS>(B.job[j], local % groups, local / groups);
 }
 
-template <int CO, int CI, bool GATHER, bool MX>
+template <int CO, int CI, bool GATHER, bool MX, int NS>
 __global__ __launch_bounds__(256, 2) void pw_wgrad3_batch_kernel(const WgBatch B) {
     int j = 0;
     while (j + 1 < B.njobs && (int)blockIdx.x >= B.wg0[j + 1]) ++j;
     const int local = (int)blockIdx.x - B.wg0[j];
     const int groups = B.job[j].groups;
-    wgrad3_body<CO, CI, GATHER, MX>(B.job[j], local % groups, local / groups);
+    wgrad3_body<CO, CI, GATHER, MX, NS>(B.job[j], local % groups, local / groups);
 }
 
 static bool wgrad2_ok(int P, long long Pin, int Co, int Ci, bool strided) {
@@ -2543,8 +2573,9 @@ extern "C" int x3d_pw_bwd_tiles(int N, int Cin, int Cout, int P, int packed, int
 
 extern "C" int x3d_pw_wants_packed(int K, int M) { (void)K; (void)M; return 1; }
 
-extern "C" size_t x3d_pw_pack_floats(int K, int M, int transposed) { return pack_floats(K, M, transposed ? 2 : 3); }
-extern "C" size_t x3d_pw_pack_items(int K, int M, int transposed) { return pack_items(K, M, transposed ? 2 : 3); }
+// both orientations carry three bf16 planes (hi, mid, lo) behind the fp32 image since ABI 6 (three-term backward GEMMs)
+extern "C" size_t x3d_pw_pack_floats(int K, int M, int transposed) { (void)transposed; return pack_floats(K, M, 3); }
+extern "C" size_t x3d_pw_pack_items(int K, int M, int transposed) { (void)transposed; return pack_items(K, M, 3); }
 
 extern "C" int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int transposed, void* stream) {
     X3D_CHECK_ARG(w && wp && Cout > 0 && Cin > 0);
@@ -2553,8 +2584,8 @@ extern "C" int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int tra
     const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
     const int ldm = transposed ? 1 : Cin, ldk = transposed ? Cin : 1;
     const int mtiles = cdiv(M, 16), kgroups = cdiv(K, 16);
-    hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)cdiv((int)pack_items(K, M, transposed ? 2 : 3), 256)), dim3(256), 0,
-                       (hipStream_t)stream, w, wp, M, K, ldm, ldk, mtiles, kgroups, transposed ? 2 : 3);
+    hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)cdiv((int)pack_items(K, M, 3), 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, wp, M, K, ldm, ldk, mtiles, kgroups, 3);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }
@@ -2677,24 +2708,28 @@ extern "C" int x3d_pw_bwd_weight(const void* g, const void* a, const float* cb, 
     if (tiled) {
         // split-bf16 MFMA (3 products, ~1e-5 on dW) by default; X3D_WGRAD_F32 selects the exact fp32-MFMA kernel
         hipStream_t s3 = (hipStream_t)stream;
+        const int ns = x3d_opt(X3D_OPT_BWD_TERMS) == 2 ? 2 : 3;
         if (x3d_opt(X3D_OPT_WGRAD_F32)) {
             hipLaunchKernelGGL(pw_wgrad2_kernel, grid, block, 0, s3, A);
         } else if (A.strided) {
-            if (wg3_co(Cout) == 128) {
-                if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<128, 64, true, false>), grid, block, 0, s3, A);
-                else hipLaunchKernelGGL((pw_wgrad3_kernel<128, 32, true, false>), grid, block, 0, s3, A);
-            } else {
-                if (wg3_ci(Cin) == 64) hipLaunchKernelGGL((pw_wgrad3_kernel<64, 64, true, false>), grid, block, 0, s3, A);
-                else hipLaunchKernelGGL((pw_wgrad3_kernel<64, 32, true, false>), grid, block, 0, s3, A);
-            }
-        } else {
-#define WG3_GO(CO_, CI_)                                                                                       \
+#define WG3S_GO(CO_, CI_)                                                                                      \
     do {                                                                                                       \
-        if (mx) hipLaunchKernelGGL((pw_wgrad3_kernel<CO_, CI_, false, true>), grid, block, 0, s3, A);           \
-        else hipLaunchKernelGGL((pw_wgrad3_kernel<CO_, CI_, false, false>), grid, block, 0, s3, A);             \
+        if (ns == 2) hipLaunchKernelGGL((pw_wgrad3_kernel<CO_, CI_, true, false, 2>), grid, block, 0, s3, A);   \
+        else hipLaunchKernelGGL((pw_wgrad3_kernel<CO_, CI_, true, false, 3>), grid, block, 0, s3, A);           \
     } while (0)
+            if (wg3_co(Cout) == 128) { if (wg3_ci(Cin) == 64) WG3S_GO(128, 64); else WG3S_GO(128, 32); }
+            else { if (wg3_ci(Cin) == 64) WG3S_GO(64, 64); else WG3S_GO(64, 32); }
+#undef WG3S_GO
+        } else {
+#define WG3_GO2(CO_, CI_, NS_)                                                                                 \
+    do {                                                                                                       \
+        if (mx) hipLaunchKernelGGL((pw_wgrad3_kernel<CO_, CI_, false, true, NS_>), grid, block, 0, s3, A);      \
+        else hipLaunchKernelGGL((pw_wgrad3_kernel<CO_, CI_, false, false, NS_>), grid, block, 0, s3, A);        \
+    } while (0)
+#define WG3_GO(CO_, CI_) do { if (ns == 2) WG3_GO2(CO_, CI_, 2); else WG3_GO2(CO_, CI_, 3); } while (0)
             if (wg3_co(Cout) == 128) { if (wg3_ci(Cin) == 64) WG3_GO(128, 64); else WG3_GO(128, 32); }
             else { if (wg3_ci(Cin) == 64) WG3_GO(64, 64); else WG3_GO(64, 32); }
+#undef WG3_GO2
 #undef WG3_GO
         }
         X3D_LAUNCH_CHECK();
@@ -2727,6 +2762,7 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
     X3D_CHECK_ARG(jobs && njobs > 0);
     hipStream_t s = (hipStream_t)stream;
     const bool f32 = x3d_opt(X3D_OPT_WGRAD_F32) != 0;
+    const int ns = x3d_opt(X3D_OPT_BWD_TERMS) == 2 ? 2 : 3;
     // variant id: bit 0 = CI 64, bit 1 = CO 128, bit 2 = gathered (strided) input; -1 = not a wgrad3 shape
     // + 10: the mixed-storage builds of the same variants.  Their storage flags are per job, so when ANY job of the call
     // has a bf16 tensor the whole call runs on them -- one launch per tile variant either way (splitting the batch by
@@ -2741,46 +2777,53 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
         const bool mxb = vv >= 10;
         const int v = vv % 10;
         const dim3 grid(b.wg0[b.njobs]), block(256);
-        if (v >= 8) {               // wide tiles: 8 waves, dynamic LDS (two planes of dY and of the input)
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<256, 96, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 96) * W3_LD * 2);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<128, 224, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 224) * W3_LD * 2);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<256, 96, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 96) * W3_LD * 2);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<128, 224, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 224) * W3_LD * 2);
-                attr_done = true;
-            }
-            const size_t l1 = 2 * (256 + 96) * W3_LD * 2, l2 = 2 * (128 + 224) * W3_LD * 2;
-            if (v == 8) {
-                if (mxb) hipLaunchKernelGGL((pw_wgrad4_batch_kernel<256, 96, true>), grid, dim3(512), l1, s, b);
-                else hipLaunchKernelGGL((pw_wgrad4_batch_kernel<256, 96, false>), grid, dim3(512), l1, s, b);
-            } else {
-                if (mxb) hipLaunchKernelGGL((pw_wgrad4_batch_kernel<128, 224, true>), grid, dim3(512), l2, s, b);
-                else hipLaunchKernelGGL((pw_wgrad4_batch_kernel<128, 224, false>), grid, dim3(512), l2, s, b);
-            }
+        if (v >= 8) {               // wide tiles: 8 waves, dynamic LDS (NS planes of dY and of the input)
+            const size_t l1 = (size_t)ns * (256 + 96) * W3_LD * 2, l2 = (size_t)ns * (128 + 224) * W3_LD * 2;
+#define WB4_GO(CO_, CI_, MX_, NS_, LDS_)                                                                                 \
+    do {                                                                                                                \
+        static bool attr_done = false;                                                                                  \
+        if (!attr_done) {                                                                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad4_batch_kernel<CO_, CI_, MX_, NS_>),        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, NS_ * (CO_ + CI_) * W3_LD * 2);        \
+            attr_done = true;                                                                                           \
+        }                                                                                                               \
+        hipLaunchKernelGGL((pw_wgrad4_batch_kernel<CO_, CI_, MX_, NS_>), grid, dim3(512), LDS_, s, b);                   \
+    } while (0)
+#define WB4_GO2(CO_, CI_, LDS_)                                                                                          \
+    do {                                                                                                                \
+        if (ns == 2) { if (mxb) WB4_GO(CO_, CI_, true, 2, LDS_); else WB4_GO(CO_, CI_, false, 2, LDS_); }                \
+        else { if (mxb) WB4_GO(CO_, CI_, true, 3, LDS_); else WB4_GO(CO_, CI_, false, 3, LDS_); }                        \
+    } while (0)
+            if (v == 8) WB4_GO2(256, 96, l1); else WB4_GO2(128, 224, l2);
+#undef WB4_GO2
+#undef WB4_GO
             b.njobs = 0;
             X3D_LAUNCH_CHECK();
             return X3D_OK;
         }
-#define WB_GO(CO_, CI_)                                                                                         \
+#define WB_GO2(CO_, CI_, NS_)                                                                                     \
     do {                                                                                                        \
-        if (mxb) hipLaunchKernelGGL((pw_wgrad3_batch_kernel<CO_, CI_, false, true>), grid, block, 0, s, b);      \
-        else hipLaunchKernelGGL((pw_wgrad3_batch_kernel<CO_, CI_, false, false>), grid, block, 0, s, b);         \
+        if (mxb) hipLaunchKernelGGL((pw_wgrad3_batch_kernel<CO_, CI_, false, true, NS_>), grid, block, 0, s, b); \
+        else hipLaunchKernelGGL((pw_wgrad3_batch_kernel<CO_, CI_, false, false, NS_>), grid, block, 0, s, b);    \
+    } while (0)
+#define WB_GO(CO_, CI_) do { if (ns == 2) WB_GO2(CO_, CI_, 2); else WB_GO2(CO_, CI_, 3); } while (0)
+#define WBS_GO(CO_, CI_)                                                                                         \
+    do {                                                                                                        \
+        if (ns == 2) hipLaunchKernelGGL((pw_wgrad3_batch_kernel<CO_, CI_, true, false, 2>), grid, block, 0, s, b); \
+        else hipLaunchKernelGGL((pw_wgrad3_batch_kernel<CO_, CI_, true, false, 3>), grid, block, 0, s, b);       \
     } while (0)
         switch (v) {
             case 0: WB_GO(64, 32); break;
             case 1: WB_GO(64, 64); break;
             case 2: WB_GO(128, 32); break;
             case 3: WB_GO(128, 64); break;
-            case 4: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 32, true, false>), grid, block, 0, s, b); break;
-            case 5: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<64, 64, true, false>), grid, block, 0, s, b); break;
-            case 6: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 32, true, false>), grid, block, 0, s, b); break;
-            default: hipLaunchKernelGGL((pw_wgrad3_batch_kernel<128, 64, true, false>), grid, block, 0, s, b); break;
+            case 4: WBS_GO(64, 32); break;
+            case 5: WBS_GO(64, 64); break;
+            case 6: WBS_GO(128, 32); break;
+            default: WBS_GO(128, 64); break;
         }
+#undef WBS_GO
+#undef WB_GO2
 #undef WB_GO
         b.njobs = 0;
         X3D_LAUNCH_CHECK();

@@ -237,7 +237,10 @@ struct P7Args {
     int N, K, M, P, tiles, T, H, W, Ho, Wo, mblocks, mt_run;
 };
 
-template <int EPI, int NPASS, bool MX>
+// NS: bf16 terms per fp32 operand -- 3 (hi + mid + lo = all 24 significant bits, six MFMA products: fp32-level, as pw6; the
+// default) or 2 (hi + lo, three products, ~2^-16 per product; option bwd_terms = 2).  The transposed pack always carries
+// three planes; the two-term form reads hi and mid (mid = bf16(v - hi) is exactly its "lo").
+template <int EPI, int NPASS, bool MX, int NS>
 __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const P7Args A) {
     const int ga_bf = MX ? A.ga_bf : 0, y_bf = MX ? A.y_bf : 0, ex_bf = MX ? A.ex_bf : 0;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
@@ -247,7 +250,8 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
     const int K = A.K, P = A.P, M = A.M;
     const int kg32 = (K + 31) / 32, kg16 = (K + 15) / 16, Kp = kg32 * 32;
     __bf16* Dh = lds6;
-    __bf16* Dl = lds6 + (size_t)Kp * P6_LD;
+    __bf16* Dm = lds6 + (size_t)Kp * P6_LD;                   // NS = 2: the second (last) plane
+    __bf16* Dl = lds6 + (size_t)(NS - 1) * Kp * P6_LD;
 
     const int VT = A.N * A.tiles;
     const int it = blockIdx.x;
@@ -284,18 +288,24 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
                 const bool ok = pvv && row < K;
                 const float4 gw = widen4(rg[i], ga_bf), aw = widen4(ra[i], ga_bf);
                 const float gv[4] = {gw.x, gw.y, gw.z, gw.w}, av[4] = {aw.x, aw.y, aw.z, aw.w};
-                bf16x2 he, ho, le, lo;
+                bf16x2 he, ho, me, mo, le, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x0 = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
                     const __bf16 h = (__bf16)x0;
-                    const __bf16 l = (__bf16)(x0 - (float)h);
-                    if (e & 1) { ho[e >> 1] = h; lo[e >> 1] = l; } else { he[e >> 1] = h; le[e >> 1] = l; }
+                    const float r1 = x0 - (float)h;
+                    const __bf16 m = (__bf16)r1;
+                    const __bf16 l = (__bf16)(r1 - (float)m);
+                    if (e & 1) { ho[e >> 1] = h; mo[e >> 1] = m; lo[e >> 1] = l; } else { he[e >> 1] = h; me[e >> 1] = m; le[e >> 1] = l; }
                 }
                 *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colE]) = he;
                 *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colO]) = ho;
-                *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colE]) = le;
-                *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colO]) = lo;
+                *reinterpret_cast<bf16x2*>(&Dm[row * P6_LD + colE]) = me;
+                *reinterpret_cast<bf16x2*>(&Dm[row * P6_LD + colO]) = mo;
+                if (NS == 3) {
+                    *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colE]) = le;
+                    *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colO]) = lo;
+                }
             }
         }
     }
@@ -307,14 +317,15 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
     const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
     const size_t plane = (size_t)mtiles * kg32 * 512;
     const __bf16* wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;
-    bf16x8 ah[4], al[4];
-    auto fetch_a = [&](int s, bf16x8& h, bf16x8& l) {
+    bf16x8 ah[4], am[4], al[4];
+    auto fetch_a = [&](int s, bf16x8& h, bf16x8& m, bf16x8& l) {
         const int sc = min(s, kg32 - 1);
         h = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512);
-        l = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512 + plane);
+        m = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512 + plane);
+        if (NS == 3) l = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512 + 2 * plane);
     };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fetch_a(i, ah[i], al[i]);
+    for (int i = 0; i < 4; ++i) fetch_a(i, ah[i], am[i], al[i]);
 
     const int pl = pt + 2 * r;                    // lane (q, r): rows 4 q + e of the tile, voxels 2 r, 2 r + 1
     const bool pv = pl < P;                       // P even: both voxels or none
@@ -374,12 +385,18 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
         const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * P6_LD));
         return cat8_(v0, v1);
     };
-    auto step = [&](int s, const bf16x8& h, const bf16x8& l) {
+    auto step = [&](int s, const bf16x8& h, const bf16x8& m, const bf16x8& l) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
-            const bf16x8 bh = tr_frag(Dh, s, h2), bl = tr_frag(Dl, s, h2);
-            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l, bh, acc[h2], 0, 0, 0);
-            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bl, acc[h2], 0, 0, 0);
+            const bf16x8 bh = tr_frag(Dh, s, h2), bm = tr_frag(Dm, s, h2);
+            if (NS == 3) {                        // smallest terms first, as pw6
+                const bf16x8 bl = tr_frag(Dl, s, h2);
+                acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l, bh, acc[h2], 0, 0, 0);
+                acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bl, acc[h2], 0, 0, 0);
+                acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m, bm, acc[h2], 0, 0, 0);
+            }
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m, bh, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bm, acc[h2], 0, 0, 0);
             acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bh, acc[h2], 0, 0, 0);
         }
     };
@@ -388,8 +405,8 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (s0 + i < kg32) {
-                    step(s0 + i, ah[i], al[i]);
-                    if (s0 + i + 4 < kg32) fetch_a(s0 + i + 4, ah[i], al[i]);
+                    step(s0 + i, ah[i], am[i], al[i]);
+                    if (s0 + i + 4 < kg32) fetch_a(s0 + i + 4, ah[i], am[i], al[i]);
                 }
             }
         }
@@ -478,7 +495,8 @@ bool x3d_pw7_ok(int K, int M, int P, int mx) {
     // measured at the base shape: K = 216 -> M = 96 (conv1 of stage 3) is the one layer where the chunked pw5_kernel is
     // not slower (23.6 vs 24.9 us: six of the eight waves own an M tile, seven k steps of staging for each)
     // (the mixed-storage mode has no chunked kernel: always here)
-    if (!mx && K > 128 && K < 256 && M <= 96) return false;
+    // (with three-term operands, the default, pw5 is not an alternative: it is a two-term kernel)
+    if (!mx && K > 128 && K < 256 && M <= 96 && x3d_opt(X3D_OPT_BWD_TERMS) == 2) return false;
     return !off && !x3d_opt(X3D_OPT_DGRAD_F32) && K >= 64 && K <= P6_RP * P6_MAXPASS && M >= 96 && (P % 4 == 0) && P >= 4;
 }
 
@@ -497,18 +515,20 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
     const int VT = N * A.tiles;
     const dim3 grid(cdiv(VT, 8) * 8 * A.mblocks), block(P6_NT);
     const int kp = cdiv(K, 32) * 32;
-    const size_t lds = (size_t)2 * kp * P6_LD * sizeof(__bf16);
+    const int ns = x3d_opt(X3D_OPT_BWD_TERMS) == 2 ? 2 : 3;
+    const size_t lds = (size_t)ns * kp * P6_LD * sizeof(__bf16);
     const int npass = cdiv(kp, P6_RP);
-#define P7_GO(EPI_, NP, MX_)                                                                                        \
+#define P7_GO2(EPI_, NP, MX_, NS_)                                                                                  \
     do {                                                                                                            \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP, MX_>),                     \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P6_RP * NP * P6_LD * 2);       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP, MX_, NS_>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, NS_ * P6_RP * NP * P6_LD * 2);     \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL((pw7_kernel<EPI_, NP, MX_>), grid, block, lds, s, A);                                     \
+        hipLaunchKernelGGL((pw7_kernel<EPI_, NP, MX_, NS_>), grid, block, lds, s, A);                                \
     } while (0)
+#define P7_GO(EPI_, NP, MX_) do { if (ns == 2) P7_GO2(EPI_, NP, MX_, 2); else P7_GO2(EPI_, NP, MX_, 3); } while (0)
 #define P7_PASS(EPI_, MX_)                                                                                           \
     do {                                                                                                             \
         if (npass <= 2) P7_GO(EPI_, 2, MX_); else if (npass <= 4) P7_GO(EPI_, 4, MX_); else P7_GO(EPI_, 7, MX_);     \
@@ -520,6 +540,7 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
     }
 #undef P7_PASS
 #undef P7_GO
+#undef P7_GO2
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

@@ -64,9 +64,35 @@ __device__ __forceinline__ bf16x8 cat8(bf16x4 lo4, bf16x4 hi4) {
 // the global round trips of one workgroup are covered by the other 3-4 resident on the CU.
 // MX: mixed-storage build (BASELINE config 5): 0 = every tensor fp32; 1 = x and dx are bf16 (conv3 of a bottleneck: the wide
 // Cmid tensors are its input side); 2 = g and a are bf16 (conv1: the wide tensors are its output side).
-template <int CO, int CI, int EPI, bool ADD, int NWV, int OCC, int MX>
+// NS: bf16 terms per fp32 operand of both GEMMs -- 3 (hi + mid + lo = all 24 significant bits, six MFMA products per tile
+// step: fp32-level accuracy, the default) or 2 (hi + mid, three products, ~2^-16 per product: option bwd_terms = 2).
+
+// rows of the raw fp32 epilogue tiles (x / ex / addend).  The widest shape (128 x 64: conv1 of stage 2, 48 input channels
+// in X3D-S/M/L) keeps 48 -- what lets all three weight planes of that shape stay in LDS; x3d_pw_bwd_fused_ok refuses
+// more input channels there
+constexpr int fb_raw_rows(int CO, int CI) { return (CO == 128 && CI == 64) ? 48 : CI; }
+
+// LDS bytes of one instantiation with WP weight planes in LDS (the kernel's __shared__ arrays, in declaration order)
+constexpr int fb_lds_bytes(int CO, int CI, int EPI, bool ADD, int NWV, int NS, int WP) {
+    const int MP = NWV / 2, U = (CI / 16 + MP - 1) / MP, KS = CO / 32, CR = fb_raw_rows(CO, CI);
+    return NS * (CO + CI) * F_LD * 2 + ((EPI == FE_PLAIN) ? 4 : NWV * U * 16 * 2) * 4 + (CI / 16) * KS * WP * 64 * 8 * 2 +
+           ((EPI == FE_ACTBWD) ? CR * F_RL : 4) * 4 + ((EPI == FE_RESBWD) ? CR * F_RL : 4) * 4 + (ADD ? CR * F_RL : 4) * 4 +
+           ((EPI == FE_ACTBWD) ? CI : 1) * 8;
+}
+constexpr int FB_LDS_MAX = 160 * 1024;
+// is (CO, CI, epilogue, addend) built for NS terms?  (the lo weight plane may move to registers, nothing else gives)
+constexpr bool fb_fits(int CO, int CI, int EPI, bool ADD, int NWV, int NS) {
+    return fb_lds_bytes(CO, CI, EPI, ADD, NWV, NS, 2) <= FB_LDS_MAX;
+}
+
+template <int CO, int CI, int EPI, bool ADD, int NWV, int OCC, int MX, int NS>
 __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArgs A) {
     constexpr int GA_BF = MX == 2, X_BF = MX == 1, DX_BF = MX == 1;
+    // weight planes kept in LDS: all NS of them when that fits, else hi + mid with the lo plane's fragments held in
+    // registers for the workgroup's life (the two widest stage-2 shapes; loaded once, before the chunk loop)
+    constexpr int WP = fb_lds_bytes(CO, CI, EPI, ADD, NWV, NS, NS) <= FB_LDS_MAX ? NS : 2;
+    constexpr int CR = fb_raw_rows(CO, CI);                // rows of the raw epilogue tiles (>= Ci: checked by the host)
+    static_assert(fb_fits(CO, CI, EPI, ADD, NWV, NS), "LDS budget: x3d_pw_bwd_fused_ok must refuse this combination");
     constexpr int NT = 64 * NWV;                           // threads
     constexpr int RP = NT / 16;                            // rows staged per pass (16 lanes x float4 = one 64-voxel row)
     constexpr int ND = (CO + RP - 1) / RP, NX = (CI + RP - 1) / RP;   // staged float4 slots per thread (dY rows, X rows)
@@ -80,17 +106,18 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
     static_assert(CO % 32 == 0 && CI % 32 == 0, "tile shape");
     static_assert(WCO * WCI == NWV && MW * WCO * 16 == CO && NW * WCI * 16 == CI, "weight-gradient tiling");
 
-    __shared__ __attribute__((aligned(16))) __bf16 Dh[CO * F_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Dlo[CO * F_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Xh[CI * F_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Xlo[CI * F_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Dp[NS * CO * F_LD];          // dY planes: hi, mid(, lo)
+    __shared__ __attribute__((aligned(16))) __bf16 Xp[NS * CI * F_LD];          // X planes
+    __bf16* const Dh = Dp; __bf16* const Dm = Dp + CO * F_LD; __bf16* const Dlo = Dp + (NS - 1) * CO * F_LD;
+    __bf16* const Xh = Xp; __bf16* const Xm = Xp + CI * F_LD; __bf16* const Xlo = Xp + (NS - 1) * CI * F_LD;
     __shared__ float red[(EPI == FE_PLAIN) ? 4 : NWV * U * 16 * 2];
-    __shared__ __attribute__((aligned(16))) __bf16 Wl[(CI / 16) * KS * 2 * 64 * 8];
+    __shared__ __attribute__((aligned(16))) __bf16 Wl[(CI / 16) * KS * WP * 64 * 8];
     // epilogue operands of the chunk, staged raw (fp32, natural voxel order) with the same coalesced row loads as the
-    // GEMM operands: x (activation backward / ReLU mask / statistics), ex, dense addend
-    __shared__ __attribute__((aligned(16))) float Xr[(EPI != FE_PLAIN) ? CI * F_RL : 4];
-    __shared__ __attribute__((aligned(16))) float Er[(EPI == FE_RESBWD) ? CI * F_RL : 4];
-    __shared__ __attribute__((aligned(16))) float Ar[ADD ? CI * F_RL : 4];
+    // GEMM operands: x (activation backward + statistics; the residual mode takes its ReLU mask from the sign of the hi
+    // plane of X instead -- x > 0 exactly when bf16(x) > 0 for every normal x -- and stages no raw x), ex, dense addend
+    __shared__ __attribute__((aligned(16))) float Xr[(EPI == FE_ACTBWD) ? CR * F_RL : 4];
+    __shared__ __attribute__((aligned(16))) float Er[(EPI == FE_RESBWD) ? CR * F_RL : 4];
+    __shared__ __attribute__((aligned(16))) float Ar[ADD ? CR * F_RL : 4];
     __shared__ float2 Cf[(EPI == FE_ACTBWD) ? CI : 1];     // per-row BN coefficients of the chunk's sample (activation backward)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,18 +135,24 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
     // LDS column of voxel c4 (even) / c4 + 1 (odd); c4 + 2 / c4 + 3 follow at + 1
     const int colE = (c4 & 32) + ((c4 & 31) >> 1), colO = colE + 16;
 
-    auto put = [&](__bf16* plane_h, __bf16* plane_l, int row, const float (&v)[4]) {
-        bf16x2 he, ho, le, lo;
+    auto put = [&](__bf16* plane_h, __bf16* plane_m, __bf16* plane_l, int row, const float (&v)[4]) {
+        bf16x2 he, ho, me, mo, le, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const __bf16 h = (__bf16)v[e];
-            const __bf16 l = (__bf16)(v[e] - (float)h);
-            if (e & 1) { ho[e >> 1] = h; lo[e >> 1] = l; } else { he[e >> 1] = h; le[e >> 1] = l; }
+            const float r1 = v[e] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            const __bf16 l = (__bf16)(r1 - (float)m);
+            if (e & 1) { ho[e >> 1] = h; mo[e >> 1] = m; lo[e >> 1] = l; } else { he[e >> 1] = h; me[e >> 1] = m; le[e >> 1] = l; }
         }
         *reinterpret_cast<bf16x2*>(&plane_h[row * F_LD + colE]) = he;
         *reinterpret_cast<bf16x2*>(&plane_h[row * F_LD + colO]) = ho;
-        *reinterpret_cast<bf16x2*>(&plane_l[row * F_LD + colE]) = le;
-        *reinterpret_cast<bf16x2*>(&plane_l[row * F_LD + colO]) = lo;
+        *reinterpret_cast<bf16x2*>(&plane_m[row * F_LD + colE]) = me;
+        *reinterpret_cast<bf16x2*>(&plane_m[row * F_LD + colO]) = mo;
+        if (NS == 3) {
+            *reinterpret_cast<bf16x2*>(&plane_l[row * F_LD + colE]) = le;
+            *reinterpret_cast<bf16x2*>(&plane_l[row * F_LD + colO]) = lo;
+        }
     };
 
     // global -> registers (fetch, issued one chunk ahead) -> (BN-backward combine | forward prologue) -> split-bf16 LDS images
@@ -192,15 +225,15 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
-            if (CO % RP == 0 || row0 + RP * i < CO) put(Dh, Dlo, row0 + RP * i, v);
+            if (CO % RP == 0 || row0 + RP * i < CO) put(Dh, Dm, Dlo, row0 + RP * i, v);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const bool ok = pvv && (row0 + RP * i < Ci);
             float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
-            if (CI % RP == 0 || row0 + RP * i < CI) {
-                if (EPI != FE_PLAIN) *reinterpret_cast<float4*>(&Xr[(row0 + RP * i) * F_RL + c4]) = rx[i];
-                if (EPI == FE_ACTBWD && c4 == 0) Cf[row0 + RP * i] = make_float2(sc[i], sh[i]);
+            if (EPI == FE_ACTBWD && c4 == 0 && (CI % RP == 0 || row0 + RP * i < CI)) Cf[row0 + RP * i] = make_float2(sc[i], sh[i]);
+            if ((CR % RP == 0 && CR == CI) || row0 + RP * i < CR) {
+                if (EPI == FE_ACTBWD) *reinterpret_cast<float4*>(&Xr[(row0 + RP * i) * F_RL + c4]) = rx[i];
                 if (EPI == FE_RESBWD) *reinterpret_cast<float4*>(&Er[(row0 + RP * i) * F_RL + c4]) = rex[i];
                 if (ADD) {
                     float4 av4 = radd[i];
@@ -217,7 +250,7 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-            if (CI % RP == 0 || row0 + RP * i < CI) put(Xh, Xlo, row0 + RP * i, v);
+            if (CI % RP == 0 || row0 + RP * i < CI) put(Xh, Xm, Xlo, row0 + RP * i, v);
         }
     };
 
@@ -232,22 +265,30 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
     auto compute_w = [&]() {
 #pragma unroll
         for (int s = 0; s < F_PT / 32; ++s) {
-            bf16x8 ah[MW], al[MW];
+            bf16x8 ah[MW], am[MW], al[MW];
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
                 const int off = ((wco0 + i) * 16 + r) * F_LD + s * 32 + 8 * q;
                 ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
-                al[i] = *reinterpret_cast<const bf16x8*>(&Dlo[off]);
+                am[i] = *reinterpret_cast<const bf16x8*>(&Dm[off]);
+                if (NS == 3) al[i] = *reinterpret_cast<const bf16x8*>(&Dlo[off]);
             }
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const int off = ((wci0 + j) * 16 + r) * F_LD + s * 32 + 8 * q;
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Xh[off]);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Xm[off]);
+                bf16x8 bl;
+                if (NS == 3) bl = *reinterpret_cast<const bf16x8*>(&Xlo[off]);
 #pragma unroll
                 for (int i = 0; i < MW; ++i) {
-                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, wacc[i][j], 0, 0, 0);
-                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, wacc[i][j], 0, 0, 0);
+                    if (NS == 3) {                     // smallest terms first
+                        wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, wacc[i][j], 0, 0, 0);
+                        wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, wacc[i][j], 0, 0, 0);
+                        wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bm, wacc[i][j], 0, 0, 0);
+                    }
+                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh, wacc[i][j], 0, 0, 0);
+                    wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm, wacc[i][j], 0, 0, 0);
                     wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, wacc[i][j], 0, 0, 0);
                 }
             }
@@ -257,16 +298,30 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
     // ---- data gradient: units (ci tile (wave >> 1) + MP j, 32-voxel half wave & 1), channel index on K
     const int mtiles = (Ci + 15) / 16, kg16 = (Co + 15) / 16, kg32 = (Co + 31) / 32;
     const __bf16* wqh = reinterpret_cast<const __bf16*>(A.wpt + (size_t)mtiles * kg16 * 256);
-    const __bf16* wql = wqh + (size_t)mtiles * kg32 * 512;
+    const size_t wplane = (size_t)mtiles * kg32 * 512;                         // pack planes: hi, mid, lo
     f32x4 dacc[U][2];
     // A operand (transposed weights, pre-split, MFMA fragment order): chunk invariant -- copied once into LDS
     // ([ci tile][k step][plane][lane][8]), one ds_read_b128 per fragment and chunk instead of 8 registers per fragment
-    for (int i = tid; i < (CI / 16) * KS * 2 * 64; i += NT) {
-        const int ln = i & 63, pl = (i >> 6) & 1, rest = i >> 7;
+    for (int i = tid; i < (CI / 16) * KS * WP * 64; i += NT) {
+        const int ln = i & 63, rest0 = i >> 6;
+        const int pl = rest0 % WP, rest = rest0 / WP;
         const int s = rest % KS, mt = rest / KS;
         const int mtc = min(mt, mtiles - 1), sc_ = min(s, kg32 - 1);          // clamped: never stored / zero dY rows
         const size_t off = (((size_t)mtc * kg32 + sc_) * 64 + ln) * 8;
-        *reinterpret_cast<bf16x8*>(&Wl[(size_t)i * 8]) = *reinterpret_cast<const bf16x8*>((pl ? wql : wqh) + off);
+        *reinterpret_cast<bf16x8*>(&Wl[(size_t)i * 8]) = *reinterpret_cast<const bf16x8*>(wqh + pl * wplane + off);
+    }
+    // the lo plane's fragments of this wave's units when they do not fit the LDS (WP < NS): registers, loaded once
+    bf16x8 alo[(WP < NS) ? U : 1][(WP < NS) ? KS : 1];
+    if (WP < NS) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int mtc = min(min(mpar + MP * j, CI / 16 - 1), mtiles - 1);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int sc_ = min(s, kg32 - 1);
+                alo[j][s] = *reinterpret_cast<const bf16x8*>(wqh + 2 * wplane + (((size_t)mtc * kg32 + sc_) * 64 + lane) * 8);
+            }
+        }
     }
 
     // transposed fragment of the dY image: lane (col i = lane & 15, k group g = lane >> 4) gets dY[32 s + 8 g + 0..7][col]
@@ -285,22 +340,43 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
         for (int j = 0; j < U; ++j) { dacc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dacc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            bf16x8 bh[2], bl[2];
+            if (NS == 2) {
+                bf16x8 bh[2], bm[2];
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                bh[h2] = tr_frag(Dh, s, h2);
-                bl[h2] = tr_frag(Dlo, s, h2);
-            }
+                for (int h2 = 0; h2 < 2; ++h2) { bh[h2] = tr_frag(Dh, s, h2); bm[h2] = tr_frag(Dm, s, h2); }
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int mtl_ = min(mpar + MP * j, CI / 16 - 1);
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * 2 + 0) * 64 + lane) * 8]);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * 2 + 1) * 64 + lane) * 8]);
+                for (int j = 0; j < U; ++j) {
+                    const int mtl_ = min(mpar + MP * j, CI / 16 - 1);
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * WP + 0) * 64 + lane) * 8]);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * WP + 1) * 64 + lane) * 8]);
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[h2], dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[h2], dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[h2], dacc[j][h2], 0, 0, 0);
+                    }
+                }
+            } else {
+                // three terms: one 16-voxel column tile at a time (three B fragments live instead of six; U is 1 for every
+                // shape of the network, so the A fragments are read once per column tile)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
-                    dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[h2], dacc[j][h2], 0, 0, 0);
-                    dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[h2], dacc[j][h2], 0, 0, 0);
-                    dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[h2], dacc[j][h2], 0, 0, 0);
+                    const bf16x8 bh = tr_frag(Dh, s, h2), bm = tr_frag(Dm, s, h2), bl = tr_frag(Dlo, s, h2);
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        const int mtl_ = min(mpar + MP * j, CI / 16 - 1);
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * WP + 0) * 64 + lane) * 8]);
+                        const bf16x8 am = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * WP + 1) * 64 + lane) * 8]);
+                        bf16x8 al;
+                        if (WP == 3) al = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * WP + 2) * 64 + lane) * 8]);
+                        else al = alo[(WP < NS) ? j : 0][(WP < NS) ? s : 0];
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, dacc[j][h2], 0, 0, 0);      // smallest terms first
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, dacc[j][h2], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -328,14 +404,21 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
                     const float2 c2 = Cf[ml];
                     esc = c2.x; esh = c2.y;
                 }
+                const int mr = CR < CI ? min(ml, CR - 1) : ml;       // raw-tile row (rows >= Ci are masked by mv)
                 if (ADD) {
-                    const float2 a2 = *reinterpret_cast<const float2*>(&Ar[ml * F_RL + vl]);
+                    const float2 a2 = *reinterpret_cast<const float2*>(&Ar[mr * F_RL + vl]);
                     v[0] += pv ? a2.x : 0.f; v[1] += pv ? a2.y : 0.f;
                 }
                 if (EPI != FE_PLAIN) {
-                    const float2 x2 = *reinterpret_cast<const float2*>(&Xr[ml * F_RL + vl]);
-                    float2 e2 = make_float2(0.f, 0.f);
-                    if (EPI == FE_RESBWD) e2 = *reinterpret_cast<const float2*>(&Er[ml * F_RL + vl]);
+                    float2 x2, e2 = make_float2(0.f, 0.f);
+                    if (EPI == FE_RESBWD) {
+                        // the ReLU mask of the producing block: sign of x from the hi plane of the staged X image (the
+                        // conv's input IS that block's output; voxels 2 r, 2 r + 1 of the half sit at columns r, r + 16)
+                        x2 = make_float2((float)Xh[ml * F_LD + 32 * half + r], (float)Xh[ml * F_LD + 32 * half + r + 16]);
+                        e2 = *reinterpret_cast<const float2*>(&Er[mr * F_RL + vl]);
+                    } else {
+                        x2 = *reinterpret_cast<const float2*>(&Xr[mr * F_RL + vl]);
+                    }
                     const float xa[2] = {x2.x, x2.y}, ea[2] = {e2.x, e2.y};
 #pragma unroll
                     for (int j2 = 0; j2 < 2; ++j2) {
@@ -631,18 +714,28 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
 static int fb_pad32(int c) { return (c + 31) / 32 * 32; }
 
 // residual mode: instantiated only where its three raw tiles fit the LDS (x3d_pw_bwd_fused_ok refuses the others)
-template <int CO, int CI, int NWV, int OCC, int MX>
-static void fb_launch_res(const FbArgs& A, dim3 grid, dim3 blk, hipStream_t s) {
-    if constexpr (CI <= 64) {
-        if (A.addend) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_RESBWD, true, NWV, OCC, MX>), grid, blk, 0, s, A);
-        else hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_RESBWD, false, NWV, OCC, MX>), grid, blk, 0, s, A);
+// one (epilogue, addend) pair; combinations whose LDS images do not fit are not instantiated (x3d_pw_bwd_fused_ok refuses them)
+template <int CO, int CI, int EPI, int NWV, int OCC, int MX, int NS>
+static void fb_launch_epi(const FbArgs& A, dim3 grid, dim3 blk, hipStream_t s) {
+    if (A.addend) {
+        if constexpr (fb_fits(CO, CI, EPI, true, NWV, NS))
+            hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, EPI, true, NWV, OCC, MX, NS>), grid, blk, 0, s, A);
+    } else {
+        if constexpr (fb_fits(CO, CI, EPI, false, NWV, NS))
+            hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, EPI, false, NWV, OCC, MX, NS>), grid, blk, 0, s, A);
     }
 }
 
+template <int CO, int CI, int NWV, int OCC, int MX, int NS>
+static void fb_launch_res(const FbArgs& A, dim3 grid, dim3 blk, hipStream_t s) {
+    if constexpr (CI <= 64) fb_launch_epi<CO, CI, FE_RESBWD, NWV, OCC, MX, NS>(A, grid, blk, s);
+}
+
 // MX = 1 (x and dx in bf16) is the conv3 of a bottleneck: activation backward, no addend
-template <int CO, int CI, int NWV, int OCC>
+template <int CO, int CI, int NWV, int OCC, int NS>
 static void fb_launch_mx1(const FbArgs& A, dim3 grid, dim3 blk, hipStream_t s) {
-    hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_ACTBWD, false, NWV, OCC, 1>), grid, blk, 0, s, A);
+    if constexpr (fb_fits(CO, CI, FE_ACTBWD, false, NWV, NS))
+        hipLaunchKernelGGL((pw_bwd_fused_kernel<CO, CI, FE_ACTBWD, false, NWV, OCC, 1, NS>), grid, blk, 0, s, A);
 }
 
 }  // namespace
@@ -659,6 +752,12 @@ extern "C" int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P, int mode, int has_a
     if (cop == 32 && ci != 64) return 0;           // instantiated: (32,64) (64,32) (64,64) (64,128) (128,32) (128,64)
     if (cop == 64 && !(ci == 32 || ci == 64 || ci == 128)) return 0;
     if (cop == 128 && !(ci == 32 || ci == 64)) return 0;
+    // the LDS images of this (epilogue, addend) pair must fit at the current number of operand terms (fb_fits: the
+    // launcher instantiates exactly these)
+    const int nwv = (cop == 128 || ci == 128) ? 16 : 8;
+    const int ns = x3d_opt(X3D_OPT_BWD_TERMS) == 2 ? 2 : 3;
+    if ((mode != 0 || has_addend) && Cin > fb_raw_rows(cop, ci)) return 0;       // raw epilogue tiles: see fb_raw_rows
+    if (!fb_fits(cop, ci, mode, has_addend != 0, nwv, ns)) return 0;
     return 1;
 }
 
@@ -698,23 +797,24 @@ extern "C" int x3d_pw_bwd_fused(const void* g, const void* a, const float* cb, c
     int co = fb_pad32(Cout), ci = fb_pad32(Cin);
     if (co == 96) co = 128;
     if (ci == 96) ci = 128;
-#define FB_LAUNCH2(CO_, CI_, EPI_, NWV_, OCC_, MX_)                                                                     \
+    const int ns = x3d_opt(X3D_OPT_BWD_TERMS) == 2 ? 2 : 3;
+#define FB_LAUNCH2(CO_, CI_, EPI_, NWV_, OCC_, MX_, NS_) fb_launch_epi<CO_, CI_, EPI_, NWV_, OCC_, MX_, NS_>(A, grid, blk, s)
+#define FB_LAUNCH3(CO_, CI_, NWV_, OCC_, MX_, NS_)                                                                       \
     do {                                                                                                                    \
-        if (addend) hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, EPI_, true, NWV_, OCC_, MX_>), grid, blk, 0, s, A);     \
-        else hipLaunchKernelGGL((pw_bwd_fused_kernel<CO_, CI_, EPI_, false, NWV_, OCC_, MX_>), grid, blk, 0, s, A);           \
+        if (mode == 0) FB_LAUNCH2(CO_, CI_, FE_PLAIN, NWV_, OCC_, MX_, NS_);                                                 \
+        else if (mode == 1) FB_LAUNCH2(CO_, CI_, FE_ACTBWD, NWV_, OCC_, MX_, NS_);                                           \
+        else fb_launch_res<CO_, CI_, NWV_, OCC_, MX_, NS_>(A, grid, blk, s);                                                 \
     } while (0)
-#define FB_LAUNCH3(CO_, CI_, NWV_, OCC_, MX_)                                                                            \
+#define FB_LAUNCH4(CO_, CI_, NWV_, OCC_, NS_)                                                                            \
     do {                                                                                                                    \
-        if (mode == 0) FB_LAUNCH2(CO_, CI_, FE_PLAIN, NWV_, OCC_, MX_);                                                      \
-        else if (mode == 1) FB_LAUNCH2(CO_, CI_, FE_ACTBWD, NWV_, OCC_, MX_);                                                \
-        else fb_launch_res<CO_, CI_, NWV_, OCC_, MX_>(A, grid, blk, s);                                                      \
+        if (mx == 0) FB_LAUNCH3(CO_, CI_, NWV_, OCC_, 0, NS_);                                                               \
+        else if (mx == X3D_MX_GA) FB_LAUNCH3(CO_, CI_, NWV_, OCC_, 2, NS_);                                                  \
+        else fb_launch_mx1<CO_, CI_, NWV_, OCC_, NS_>(A, grid, blk, s);                                                      \
     } while (0)
 #define FB_LAUNCH(CO_, CI_, NWV_, OCC_)                                                                                  \
     do {                                                                                                                    \
         const dim3 blk(64 * NWV_);                                                                                          \
-        if (mx == 0) FB_LAUNCH3(CO_, CI_, NWV_, OCC_, 0);                                                                    \
-        else if (mx == X3D_MX_GA) FB_LAUNCH3(CO_, CI_, NWV_, OCC_, 2);                                                       \
-        else fb_launch_mx1<CO_, CI_, NWV_, OCC_>(A, grid, blk, s);                                                           \
+        if (ns == 2) FB_LAUNCH4(CO_, CI_, NWV_, OCC_, 2); else FB_LAUNCH4(CO_, CI_, NWV_, OCC_, 3);                          \
     } while (0)
     // narrow shapes (stage 1): 4 waves, 4 workgroups per CU; wide ones (stage 2): 8 waves, 2 workgroups per CU
     if (co == 32 && ci == 64) FB_LAUNCH(32, 64, 8, 4);
@@ -724,6 +824,7 @@ extern "C" int x3d_pw_bwd_fused(const void* g, const void* a, const float* cb, c
     else if (co == 128 && ci == 32) FB_LAUNCH(128, 32, 16, 4);
     else FB_LAUNCH(128, 64, 16, 4);
 #undef FB_LAUNCH
+#undef FB_LAUNCH4
 #undef FB_LAUNCH3
 #undef FB_LAUNCH2
     X3D_LAUNCH_CHECK();

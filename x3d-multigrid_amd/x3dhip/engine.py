@@ -86,7 +86,7 @@ class WeightPacks:
             self.views[(id(w), transposed)] = view
             nwg = (items[j] + 255) // 256
             jobs[j] = (w.data_ptr(), view.data_ptr(), M, K, ldm, ldk, (M + 15) // 16, (K + 15) // 16, wg,
-                       2 if transposed else 3)      # bf16 planes behind the fp32 image: hi/lo (backward), hi/mid/lo (forward)
+                       3)      # bf16 planes behind the fp32 image: hi / mid / lo in both orientations
             wg_job += [j] * nwg
             self.ptrs.append(w.data_ptr())
             off += n
