@@ -88,7 +88,8 @@ class KernelTimer:
             e0.record()
             flush0(d)
             e1.record()
-            timer.records.append(("pw_bwd_weight", e0, e1, timer.pending_wbytes, "batched x%d" % timer.pending_wjobs))
+            timer.records.append(("pw_bwd_weight", e0, e1, timer.pending_wbytes, "batched x%d" % timer.pending_wjobs,
+                                  "pw_wgrad_batch(+reduce)"))
             timer.pending_wbytes, timer.pending_wjobs = 0, 0
 
         self._flush0 = flush0
@@ -102,7 +103,12 @@ class KernelTimer:
             setattr(self.ops, name, self._wrap(name, fn))
         return self
 
+    # entry points whose kernel template varies with the shape: the library reports which one it launched (x3d_last_kernel)
+    KERNEL_OF = {"pw_fwd", "pw_bwd_data", "pw_bwd_data_res", "pw_bwd_fused", "dw333_fwd", "dw333_fwd_stats", "dw333_bwd"}
+
     def _wrap(self, name, fn):
+        from x3dhip import _lib
+
         def inner(*a, **k):
             if name == "pw_bwd_weight" and k.get("defer") is not None:       # runs inside DeferredGrads.flush
                 self.pending_wbytes += _alg_bytes(name, a, k, None)
@@ -117,7 +123,8 @@ class KernelTimer:
                 shp += " w=" + "x".join(map(str, a[3][:2]))
             elif name.startswith("pw_"):
                 shp += " w=" + "x".join(map(str, (a[1] if name == "pw_fwd" else a[3]).shape[:2])) if name != "pw_bwd_weight" else " w=" + "x".join(map(str, a[4][:2]))
-            self.records.append((self.ALIAS.get(name, name), e0, e1, _alg_bytes(name, a, k, r), shp))
+            kern = _lib.last_kernel() if name in self.KERNEL_OF else name
+            self.records.append((self.ALIAS.get(name, name), e0, e1, _alg_bytes(name, a, k, r), shp, kern))
             return r
         return inner
 
@@ -128,15 +135,16 @@ class KernelTimer:
 
     def summary(self):
         torch.cuda.synchronize()
-        agg = {}
+        agg, self.by_kernel = {}, {}
         self.launches = []
-        for name, e0, e1, nbytes, shp in self.records:
+        for name, e0, e1, nbytes, shp, kern in self.records:
             ms_ = e0.elapsed_time(e1)
-            self.launches.append((name, shp, round(ms_, 4), round(nbytes / (ms_ * 1e-3) / 1e9, 1) if ms_ > 0 else 0))
-            d = agg.setdefault(name, [0.0, 0, 0])
-            d[0] += e0.elapsed_time(e1)
-            d[1] += nbytes
-            d[2] += 1
+            self.launches.append((name, shp, round(ms_, 4), round(nbytes / (ms_ * 1e-3) / 1e9, 1) if ms_ > 0 else 0, kern))
+            for key, table in ((name, agg), (kern, self.by_kernel)):
+                d = table.setdefault(key, [0.0, 0, 0])
+                d[0] += ms_
+                d[1] += nbytes
+                d[2] += 1
         return agg
 
 
@@ -174,34 +182,48 @@ def _alg_bytes(name, a, k, r):
     return 0
 
 
-def cpu_baseline(T, H, sample_B=2, budget_s=12.0, min_steps=3, max_steps=12):
-    """CPU oracle (port of the reference) on the host cores: fwd+bwd on a B=2 sample."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(T, H, sample_B=2, budget_s=10.0, min_steps=3, max_steps=8):
+    """CPU oracle (stock-PyTorch restatement of the reference, oracle/x3d_oracle.py) on the host cores: fwd+bwd of X3D-M on a
+    B = 2 sample of the headline clip shape, at ALL cores of this process's affinity mask and at 8 threads (SURVEY.md 8(d):
+    the 8-thread figure ties back to BASELINE.md's measurement of the reference itself in the 8-core build container)."""
     from oracle import x3d_oracle as xo
     from x3dhip import synthetic
-    # the GPU box gives one GPU a 16-core CPU share (os.cpu_count() reports the whole host):
-    # use the affinity mask, capped at 16 threads
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))        # the GPU box gives one GPU a CPU share; os.cpu_count() is the whole host
     except Exception:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
-    torch.set_num_threads(cores)
-    print("[bench] cpu baseline: oracle fwd+bwd on %d threads ..." % cores, file=sys.stderr, flush=True)
+        avail = os.cpu_count() or 1
     sd = synthetic.procedural_state_dict(xo.state_template("M", 400, 1), 0)
     x = synthetic.synthetic_clips(sample_B, T, H, H)
     y = synthetic.synthetic_labels(sample_B)
-    xo.train_step_grads(x, y, sd, "M", 1)         # warm-up
-    ts = []
-    t_begin = time.time()
-    while len(ts) < min_steps or (time.time() - t_begin < budget_s and len(ts) < max_steps):
-        t0 = time.time()
-        xo.train_step_grads(x, y, sd, "M", 1)
-        ts.append(time.time() - t0)
-        print("[bench] cpu baseline step %.2f s" % ts[-1], file=sys.stderr, flush=True)
-    t = sorted(ts)[len(ts) // 2]
-    return {"value": round(sample_B / t, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "oracle/x3d_oracle.py fwd+bwd, X3D-M B=%d T=%d H=W=%d fp32, median of %d steps, torch CPU %d threads"
-                      % (sample_B, T, H, len(ts), cores)}
+
+    def timed(threads):
+        torch.set_num_threads(threads)
+        print("[bench] cpu baseline: oracle fwd+bwd on %d threads ..." % threads, file=sys.stderr, flush=True)
+        xo.train_step_grads(x, y, sd, "M", 1)         # warm-up
+        ts, t_begin = [], time.time()
+        while len(ts) < min_steps or (time.time() - t_begin < budget_s and len(ts) < max_steps):
+            t0 = time.time()
+            xo.train_step_grads(x, y, sd, "M", 1)
+            ts.append(time.time() - t0)
+        return sorted(ts)[len(ts) // 2], len(ts)
+
+    t_all, n_all = timed(avail)
+    t_8, n_8 = timed(min(8, avail))
+    return {"value": round(sample_B / t_all, 3), "unit": "clips/s", "cores": avail, "kind": "port",
+            "value_8_threads": round(sample_B / t_8, 3), "cores_8": min(8, avail), "cpu_model": _cpu_model(),
+            "host_cpu_count": os.cpu_count(),
+            "sample": "oracle/x3d_oracle.py fwd+bwd, X3D-M B=%d T=%d H=W=%d fp32 (a B=2 sample of the B=8 workload), median of %d / %d "
+                      "steps at %d / %d torch CPU threads" % (sample_B, T, H, n_all, n_8, avail, min(8, avail))}
 
 
 def main():
@@ -335,6 +357,31 @@ def main():
                               "frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
+    # data-parallel exchange: who talked to whom, and what one bucket costs on its own -- so that the
+    # driver's 1/2/4/8-GPU curve explains itself (the per-step exchange is overlapped with the early layers' backward)
+    comm = {"rccl_ranks": world, "backend": (backend if world > 1 else None),
+            "graph_mode": ("two graphs around bucket 0 (overlap)" if (world > 1 and tr.use_graph and tr._overlap())
+                           else "single graph" if tr.use_graph else "eager"),
+            "buckets_bytes": [4 * (b_ - a_) for a_, b_ in tr.reducer.buckets]}
+    if world > 1:
+        import torch.distributed as dist
+        per = []
+        for (a_, b_) in tr.reducer.buckets:
+            buf = torch.zeros(b_ - a_, device=dev)
+            for _ in range(3):
+                dist.all_reduce(buf, group=pg)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            e0.record()
+            for _ in range(10):
+                dist.all_reduce(buf, group=pg)
+            e1.record()
+            torch.cuda.synchronize()
+            tb = torch.tensor([e0.elapsed_time(e1) / 10], device=dev, dtype=torch.float64)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            per.append(round(tb.item(), 4))
+        comm["allreduce_ms_per_bucket_standalone"] = per
+    out["data_parallel"] = comm
     if exact is not None:
         out["value_exact_fp32"] = round(exact[0], 2)
         out["ms_per_step_exact_fp32"] = round(exact[1], 3)
@@ -367,42 +414,53 @@ def main():
             with open(args.dump_launches, "w") as f:
                 json.dump(kt.launches, f)
         tot = sum(v[0] for v in agg.values())
-        dom = max(agg.items(), key=lambda kv: kv[1][0])
+        # dominant KERNEL (template name as rocprofv3 prints it; a family such as "pointwise forward" is four kernels)
+        dom = max(kt.by_kernel.items(), key=lambda kv: kv[1][0])
         name, (tms, nbytes, cnt) = dom
         ach = nbytes / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
-        traffic = None
-        # written by tools/collect_traffic.py from PMC passes (fp32 mode; the mixed-storage mode has its own collection)
-        tpath = os.path.join(ROOT, "profiles", "r02", "d_traffic_bf16_M.json") if mixed else \
-            os.path.join(ROOT, "profiles", "traffic.json")
-        if not (args.model == "M" and (B, T, H) == (8, 16, 224)):
-            tpath = ""                                              # the PMC collections are of the headline workload only
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # MFMA utilisation of the pointwise families from the committed PMC pass (tools/collect_pmc.py ->
-        # profiles/r02/*pmc_sq.json): SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CYCLES) = busy matrix pipes of the 4 per CU.
-        # north_star asks for it as evidence that the pointwise path uses the matrix cores; the bound is HBM / latency.
+        # HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes) and MFMA utilisation come from rocprofv3 counter
+        # collections committed under profiles/ (tools/collect_traffic.py, tools/collect_pmc.py): counters cannot be read from
+        # inside the run.  Each collection carries the sha of the kernel sources it was taken on; one taken on OTHER sources, or
+        # of another workload, is not reported.
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import glob
+        import stamp
+        sha = stamp.csrc_sha16()
+        headline = args.model == "M" and (B, T, H) == (8, 16, 224)
+
+        def newest(pattern):
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", pattern)), reverse=True):
+                try:
+                    d = json.load(open(f))
+                    if d.get("_meta", {}).get("csrc_sha16") == sha:
+                        return f, d
+                except Exception:
+                    pass
+            return None, None
+
+        traffic = traffic_src = None
+        tf, td = newest("*traffic_bf16_M.json" if mixed else "*traffic_f32_M.json") if headline else (None, None)
+        if td is not None:
+            traffic = td.get("_kernels", {}).get(name, {}).get("hbm_bytes_per_launch")
+            traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s)" % (os.path.relpath(tf, ROOT), td["_meta"].get("commit"))
         mfma = None
-        try:
-            import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_sq.json")))
-            if cands:
-                pm = json.load(open(cands[-1]))
-                mfma = {"source": os.path.relpath(cands[-1], ROOT),
-                        "busy_matrix_pipes_of_4_per_cu": {k: round(v["derived"]["mfma_busy_per_sq_busy"], 3)
-                                                          for k, v in pm.items()
-                                                          if k.startswith("pw_") and "mfma_busy_per_sq_busy" in v.get("derived", {})}}
-        except Exception:
-            mfma = None
+        pf, pd = newest("*pmc_sq_f32_M.json") if (headline and not mixed) else (None, None)
+        if pd is not None:
+            mfma = {"source": "%s (rocprofv3 --pmc pass at commit %s)" % (os.path.relpath(pf, ROOT), pd["_meta"].get("commit")),
+                    "busy_matrix_pipes_of_4_per_cu": {k[7:]: round(v["derived"]["mfma_busy_per_sq_busy"], 3)
+                                                      for k, v in pd.items() if k.startswith("kernel:") and
+                                                      v.get("derived", {}).get("mfma_busy_per_sq_busy", 0) > 0}}
         out["mfma_utilisation"] = mfma
         out["roofline"] = {"bound": "hbm", "kernel": name, "launches_per_step": cnt,
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_ms": round(tms / cnt, 4),
                            "alg_bytes_per_launch": int(nbytes / cnt),
-                           "share_of_step_device_time": round(tms / tot, 3)}
+                           "share_of_step_device_time": round(tms / tot, 3),
+                           "csrc_sha16": sha}
+        out["kernel_roofline"] = {k: {"launches": v[2], "ms": round(v[0], 3), "avg_launch_us": round(1e3 * v[0] / v[2], 2),
+                                      "achieved_GBs": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 and v[1] else None}
+                                  for k, v in sorted(kt.by_kernel.items(), key=lambda kv: -kv[1][0])[:12]}
         out["kernel_breakdown_ms"] = {k: [round(v[0], 3), v[2], round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0]
                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "M":

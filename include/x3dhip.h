@@ -54,6 +54,9 @@ extern "C" {
 
 int x3d_abi_version(void);
 const char* x3d_last_error(void);
+/* measurement aid: name of the kernel template (e.g. "pw6_kernel", "dw_bwd_kernel") the last pointwise / channelwise entry
+ * point called from this thread launched -- the names a rocprofv3 --kernel-trace summary prints (bench.py groups by it) */
+const char* x3d_last_kernel(void);
 
 /* Tuning / A-B options (ABI 6).  The reference has no counterpart (its only knobs are the module constants of
  * train_x3d_kinetics_multigrid.py:49-61); these select between kernels of this library that compute the same function.

@@ -324,6 +324,37 @@ def test_graph_cache_released_at_long_cycle_switches():
     assert len(tr._graphs) == 1
 
 
+def test_retired_scratch_outlives_every_captured_graph_of_the_process():
+    """Captured graphs replay into the process-wide finalize scratch by raw pointer.  A block that was outgrown is retired,
+    and may be released only when NO trainer of the process holds a graph: another trainer's invalidate_graphs() must not
+    free it under a live graph (round-2 advice), the last one's does."""
+    import x3d as resnet_x3d
+    from x3dhip import ops
+    from x3dhip.trainer import Trainer
+    dev = _dev()
+    x = synthetic.synthetic_clips(4, 2, 32, 32, seed=3).to(dev)
+    y = synthetic.synthetic_labels(4, seed=3).to(dev)
+
+    def make():
+        m = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=1).to(dev).train(True)
+        return Trainer(m, lr=0.01, use_graph=True)
+
+    a, b = make(), make()
+    a.train_step(x, y)
+    b.train_step(x, y)
+    assert a._graphs and b._graphs
+    cur = ops._scratch[dev]
+    ops.scratch(dev, cur.numel() * 2)                    # outgrow the block both graphs point into: it is retired
+    assert any(t is cur for t in ops._scratch_retired)
+    b.invalidate_graphs()                                # a's graph is still alive
+    assert any(t is cur for t in ops._scratch_retired)
+    l1, _ = a.train_step(x, y)                           # replays into the retired block
+    torch.cuda.synchronize()
+    assert float(l1) == float(l1)
+    a.invalidate_graphs()
+    assert not ops._scratch_retired
+
+
 def test_gradient_accumulation_equals_one_big_step():
     """num_steps_per_update = 2 on two half batches == the gradient of loss/2 + loss/2 (train...:267-273): the update equals
     an SGD step on the mean of the two micro-batch gradients."""

@@ -15,7 +15,8 @@ import sqlite3
 import sys
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
-from collect_traffic import fam  # noqa: E402
+from collect_traffic import fam, template_name  # noqa: E402
+import stamp  # noqa: E402
 
 
 def load_all(d):
@@ -37,6 +38,9 @@ def main():
                 if f:
                     agg[f][cname][0] += sum(vals)
                     agg[f][cname][1] += len(vals)
+                if "Cijk" not in k and "rocclr" not in k:
+                    agg["kernel:" + template_name(k)][cname][0] += sum(vals)
+                    agg["kernel:" + template_name(k)][cname][1] += len(vals)
     out = {}
     for f, cs in sorted(agg.items()):
         row = {c: {"sum": v[0], "launches": v[1], "per_launch": v[0] / max(v[1], 1)} for c, v in cs.items()}
@@ -52,7 +56,9 @@ def main():
         if g("SQ_ACTIVE_INST_VALU") is not None and g("SQ_WAVE_CYCLES"):
             der["active_inst_valu_per_wave_cycle"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")
         out[f] = {"counters": row, "derived": der}
+    out["_meta"] = stamp.meta()
     json.dump(out, open(out_path, "w"), indent=1)
+    del out["_meta"]
     for f, v in out.items():
         print("%-18s %s" % (f, "  ".join("%s=%.4g" % kv for kv in v["derived"].items())))
         print("                   " + "  ".join("%s/launch=%.4g" % (c, r["per_launch"]) for c, r in sorted(v["counters"].items())))

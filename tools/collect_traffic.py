@@ -57,23 +57,35 @@ def fam(name):
     return None
 
 
+def template_name(name):
+    """Kernel template without its arguments and namespace: what x3d_last_kernel() / bench.py's roofline.kernel report."""
+    m = re.search(r"([A-Za-z_][A-Za-z_0-9]*)(?:<[^(]*>)?\(", name)
+    return m.group(1) if m else name.split("(")[0]
+
+
 def main():
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import stamp
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    kagg = collections.defaultdict(lambda: [0.0, 0.0, 0])
     for k, vals in fetch.items():
-        f = fam(k)
-        if f:
-            agg[f][0] += 2.0 * 1024.0 * sum(vals)          # x2: gfx950 FETCH_SIZE correction, KiB -> B
-            agg[f][2] += len(vals)
+        for key, table in ((fam(k), agg), (template_name(k), kagg)):
+            if key:
+                table[key][0] += 2.0 * 1024.0 * sum(vals)          # x2: gfx950 FETCH_SIZE correction, KiB -> B
+                table[key][2] += len(vals)
     for k, vals in write.items():
-        f = fam(k)
-        if f:
-            agg[f][1] += 1024.0 * sum(vals)
-    out = {}
-    for f, (rd, wr, n) in agg.items():
-        out[f] = {"launches": n, "hbm_read_bytes_per_launch": rd / max(n, 1), "hbm_write_bytes_per_launch": wr / max(n, 1),
-                  "hbm_bytes_per_launch": (rd + wr) / max(n, 1)}
+        for key, table in ((fam(k), agg), (template_name(k), kagg)):
+            if key:
+                table[key][1] += 1024.0 * sum(vals)
+    row = lambda rd, wr, n: {"launches": n, "hbm_read_bytes_per_launch": rd / max(n, 1),
+                             "hbm_write_bytes_per_launch": wr / max(n, 1), "hbm_bytes_per_launch": (rd + wr) / max(n, 1)}
+    out = {f: row(*v) for f, v in agg.items()}
+    out["_kernels"] = {k: row(*v) for k, v in kagg.items() if "Cijk" not in k and "rocclr" not in k}
+    out["_meta"] = stamp.meta()
     json.dump(out, open(sys.argv[3], "w"), indent=1)
+    del out["_kernels"], out["_meta"]
     for f, v in sorted(out.items()):
         print("%-20s launches %5d  read %10.1f MB  write %10.1f MB per launch" %
               (f, v["launches"], v["hbm_read_bytes_per_launch"] / 1e6, v["hbm_write_bytes_per_launch"] / 1e6))

@@ -12,6 +12,12 @@ void x3d_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* x3d_last_error(void) { return g_err; }
+
+// name of the kernel template the last launching entry point of this thread chose (measurement aid: bench.py groups its
+// HIP-event timings by it, so that they line up with the kernel names of a rocprofv3 summary)
+static thread_local const char* g_last_kernel = "";
+void x3d_note_kernel(const char* name) { g_last_kernel = name; }
+extern "C" const char* x3d_last_kernel(void) { return g_last_kernel; }
 extern "C" int x3d_abi_version(void) { return X3D_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void x3d_set_error(const char* fmt, ...);
+void x3d_note_kernel(const char* name);     // x3d_last_kernel(): which kernel template an entry point launched
 
 // Options of the library (api.hip; set with x3d_set_option, include/x3dhip.h).  x3d_opt(id) is the value NOW: entry
 // points and tile-count queries read it per call, never cache it.

@@ -957,6 +957,7 @@ extern "C" int x3d_dw333_fwd(const void* x, const float* w, void* y, int N, int 
     const size_t ldsb = fwd_lds_bytes(A.g);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_fwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
+    x3d_note_kernel("dw_fwd_kernel");
     DW_DISPATCH(dw_fwd_kernel, A, A.g, ldsb, false);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
@@ -982,6 +983,7 @@ extern "C" int x3d_dw333_fwd_stats(const void* x, const float* w, void* y, int N
     const size_t ldsb = fwd_lds_bytes(A.g);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_fwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
+    x3d_note_kernel("dw_fwd_kernel");
     DW_DISPATCH(dw_fwd_kernel, A, A.g, ldsb, false);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
@@ -1004,6 +1006,7 @@ extern "C" int x3d_dw333_bwd(const void* g, const void* a, const float* cb, cons
     const size_t ldsb = bwd_lds_bytes(A.geo);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_bwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
+    x3d_note_kernel("dw_bwd_kernel");
     DW_DISPATCH(dw_bwd_kernel, A, A.geo, ldsb, true);
     X3D_LAUNCH_CHECK();
     return X3D_OK;
@@ -1028,6 +1031,7 @@ extern "C" int x3d_dw333_bwd_stats(const void* g, const void* a, const float* sp
     const size_t ldsb = bwd_lds_bytes(A.geo);
     if (ldsb > 160 * 1024) { x3d_set_error("dw333_bwd: LDS tile too large (W=%d)", W); return X3D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
+    x3d_note_kernel("dw_bwd_kernel");
     DW_DISPATCH(dw_bwd_kernel, A, A.geo, ldsb, true);
     X3D_LAUNCH_CHECK();
     return X3D_OK;

@@ -1616,12 +1616,14 @@ int launch_pw(PwArgs& A, hipStream_t s) {
             // three-term operands (the default) the shapes that reach this point -- K beyond pw7's LDS tile: X3D-XL's 630
             // channels -- run on the exact fp32-MFMA pw4 below
             constexpr int E5 = (EPI == EPI_STATS) ? EPI_PLAIN : EPI;
+            x3d_note_kernel("pw5_kernel");
             if (U <= 2) hipLaunchKernelGGL((pw5_kernel<E5, 2>), pgrid, block, 0, s, A);
             else if (U == 3) hipLaunchKernelGGL((pw5_kernel<E5, 3>), pgrid, block, 0, s, A);
             else hipLaunchKernelGGL((pw5_kernel<E5, 4>), pgrid, block, 0, s, A);
             X3D_LAUNCH_CHECK();
             return X3D_OK;
         }
+        x3d_note_kernel("pw4_kernel");
         if (U <= 2) hipLaunchKernelGGL((pw4_kernel<IN, EPI, 2>), pgrid, block, 0, s, A);
         else if (U == 3) hipLaunchKernelGGL((pw4_kernel<IN, EPI, 3>), pgrid, block, 0, s, A);
         else hipLaunchKernelGGL((pw4_kernel<IN, EPI, 4>), pgrid, block, 0, s, A);
@@ -1638,6 +1640,7 @@ int launch_pw(PwArgs& A, hipStream_t s) {
     if (variant == 2) {
         if (A.K > PW_MAXK) { x3d_set_error("pw: K=%d exceeds the coefficient table (%d)", A.K, PW_MAXK); return X3D_EINVAL; }
         const bool vec = dense && (A.P % 4 == 0);
+        x3d_note_kernel("pw2_kernel");
         if (A.mt_run > 4) {
             if (vec) hipLaunchKernelGGL((pw2_kernel<IN, EPI, true, true>), grid, block, 0, s, A);
             else hipLaunchKernelGGL((pw2_kernel<IN, EPI, false, true>), grid, block, 0, s, A);
@@ -1651,6 +1654,7 @@ int launch_pw(PwArgs& A, hipStream_t s) {
         if (mx) hipLaunchKernelGGL((pw3_kernel<MT_, NT_, IN, EPI, true>), grid, block, 0, s, A);             \
         else hipLaunchKernelGGL((pw3_kernel<MT_, NT_, IN, EPI, false>), grid, block, 0, s, A);               \
     } while (0)
+        x3d_note_kernel("pw3_kernel");
         if (A.mt_run <= 2) {
             if (variant == 0) PW3_GO(2, 4); else PW3_GO(2, 1);
         } else {
@@ -1658,9 +1662,11 @@ int launch_pw(PwArgs& A, hipStream_t s) {
         }
 #undef PW3_GO
     } else if (A.mt_run <= 2) {
+        x3d_note_kernel("pw_kernel");
         if (variant == 0) hipLaunchKernelGGL((pw_kernel<2, 4, IN, EPI>), grid, block, 0, s, A);
         else hipLaunchKernelGGL((pw_kernel<2, 1, IN, EPI>), grid, block, 0, s, A);
     } else {
+        x3d_note_kernel("pw_kernel");
         if (variant == 0) hipLaunchKernelGGL((pw_kernel<4, 4, IN, EPI>), grid, block, 0, s, A);
         else hipLaunchKernelGGL((pw_kernel<4, 1, IN, EPI>), grid, block, 0, s, A);
     }
@@ -2709,6 +2715,7 @@ extern "C" int x3d_pw_bwd_weight(const void* g, const void* a, const float* cb, 
         // split-bf16 MFMA (3 products, ~1e-5 on dW) by default; X3D_WGRAD_F32 selects the exact fp32-MFMA kernel
         hipStream_t s3 = (hipStream_t)stream;
         const int ns = x3d_opt(X3D_OPT_BWD_TERMS) == 2 ? 2 : 3;
+        x3d_note_kernel(x3d_opt(X3D_OPT_WGRAD_F32) ? "pw_wgrad2_kernel" : "pw_wgrad3_kernel");
         if (x3d_opt(X3D_OPT_WGRAD_F32)) {
             hipLaunchKernelGGL(pw_wgrad2_kernel, grid, block, 0, s3, A);
         } else if (A.strided) {
@@ -2747,6 +2754,7 @@ extern "C" int x3d_pw_bwd_weight(const void* g, const void* a, const float* cb, 
             else hipLaunchKernelGGL((pw_wgrad_kernel<CT_, IT_, false, false>), grid, block, 0, s, A);       \
         }                                                                                                  \
     } while (0)
+    x3d_note_kernel("pw_wgrad_kernel");
     if (A.ct_run <= 2 && A.it_run <= 2) WG_LAUNCH(2, 2);
     else if (A.ct_run <= 2) WG_LAUNCH(2, 4);
     else if (A.it_run <= 2) WG_LAUNCH(4, 2);
@@ -2777,6 +2785,7 @@ extern "C" int x3d_pw_bwd_weight_batch(const X3DWgradJob* jobs, int njobs, void*
         const bool mxb = vv >= 10;
         const int v = vv % 10;
         const dim3 grid(b.wg0[b.njobs]), block(256);
+        x3d_note_kernel(v >= 8 ? "pw_wgrad4_batch_kernel" : "pw_wgrad3_batch_kernel");
         if (v >= 8) {               // wide tiles: 8 waves, dynamic LDS (NS planes of dY and of the input)
             const size_t l1 = (size_t)ns * (256 + 96) * W3_LD * 2, l2 = (size_t)ns * (128 + 224) * W3_LD * 2;
 #define WB4_GO(CO_, CI_, MX_, NS_, LDS_)                                                                                 \

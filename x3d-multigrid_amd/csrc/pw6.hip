@@ -481,6 +481,7 @@ int x3d_pw6_launch(const void* x, const float* cin, const float* wp, void* y, fl
     do {                                                                                                       \
         if (npass <= 2) P6_GO(AFF, 2, MX_); else if (npass <= 4) P6_GO(AFF, 4, MX_); else P6_GO(AFF, 7, MX_);  \
     } while (0)
+    x3d_note_kernel("pw6_kernel");
     if (x_bf || y_bf) { if (cin) P6_PASS(1, true); else P6_PASS(0, true); }
     else if (cin) P6_PASS(1, false); else P6_PASS(0, false);
 #undef P6_PASS
@@ -533,6 +534,7 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
     do {                                                                                                             \
         if (npass <= 2) P7_GO(EPI_, 2, MX_); else if (npass <= 4) P7_GO(EPI_, 4, MX_); else P7_GO(EPI_, 7, MX_);     \
     } while (0)
+    x3d_note_kernel("pw7_kernel");
     if (ga_bf || y_bf || ex_bf) {
         if (mode == P7_PLAIN) P7_PASS(P7_PLAIN, true); else if (mode == P7_ACTBWD) P7_PASS(P7_ACTBWD, true); else P7_PASS(P7_RESBWD, true);
     } else {

@@ -816,6 +816,7 @@ extern "C" int x3d_pw_bwd_fused(const void* g, const void* a, const float* cb, c
         const dim3 blk(64 * NWV_);                                                                                          \
         if (ns == 2) FB_LAUNCH4(CO_, CI_, NWV_, OCC_, 2); else FB_LAUNCH4(CO_, CI_, NWV_, OCC_, 3);                          \
     } while (0)
+    x3d_note_kernel("pw_bwd_fused_kernel");
     // narrow shapes (stage 1): 4 waves, 4 workgroups per CU; wide ones (stage 2): 8 waves, 2 workgroups per CU
     if (co == 32 && ci == 64) FB_LAUNCH(32, 64, 8, 4);
     else if (co == 64 && ci == 32) FB_LAUNCH(64, 32, 8, 4);
@@ -862,6 +863,7 @@ int x3d_pwfs_launch(const void* x, const float* cin, const float* wp, void* y, f
         if (x_bf || y_bf) hipLaunchKernelGGL((pw_fwd_stream_kernel<KP_, MP_, 8, true>), grid, blk, 0, s, A);  \
         else hipLaunchKernelGGL((pw_fwd_stream_kernel<KP_, MP_, 8, false>), grid, blk, 0, s, A);              \
     } while (0)
+    x3d_note_kernel("pw_fwd_stream_kernel");
     if (kp == 32) { if (mp == 32) FS_GO(32, 32); else if (mp == 64) FS_GO(32, 64); else FS_GO(32, 128); }
     else { if (mp <= 64) FS_GO(64, 64); else FS_GO(64, 128); }
 #undef FS_GO

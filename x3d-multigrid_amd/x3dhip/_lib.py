@@ -28,6 +28,7 @@ SIGNATURES = {
     "x3d_clip_job_bytes": (_Z, []),
     "x3d_clip_preprocess": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "x3d_last_error": (ctypes.c_char_p, []),
+    "x3d_last_kernel": (ctypes.c_char_p, []),
     "x3d_set_option": (_I, [ctypes.c_char_p, _I]),
     "x3d_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "x3d_reset_options": (_I, []),
@@ -132,6 +133,11 @@ def get_option(name):
     v = ctypes.c_int(0)
     check(lib().x3d_get_option(name.encode(), ctypes.byref(v)))
     return v.value
+
+
+def last_kernel():
+    """Kernel template name the last pointwise / channelwise entry point of this thread launched (x3d_last_kernel)."""
+    return lib().x3d_last_kernel().decode()
 
 
 def option_names():

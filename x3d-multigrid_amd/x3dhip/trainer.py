@@ -8,11 +8,16 @@ the flat buffer (15.18 MB fp32 for X3D-M) and divided by the world size inside t
 kernel; BN statistics stay local to the rank (DataParallel semantics).
 """
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
 
 from . import ops
+
+# every live Trainer of the process: captured graphs hold raw pointers into the process-wide finalize scratch (ops.scratch),
+# so a retired scratch block may only be released when NO trainer holds a graph any more
+_TRAINERS = weakref.WeakSet()
 
 
 class FlatParams:
@@ -126,6 +131,7 @@ class Trainer:
         self.first = True
         self.use_graph = use_graph
         self._graphs = {}
+        _TRAINERS.add(self)
         model._direct_grads = True      # engine writes parameter gradients straight into fp.grad
         self.reducer = GradReducer(self.fp.grad, self.fp.head_first_buckets(model), world_size, process_group)
 
@@ -326,9 +332,14 @@ class Trainer:
         (update_bn_splits_long_cycle) or when parameters are re-homed.  Called from the long-cycle switch
         (train_x3d_kinetics_multigrid.run) and, as a safety net, by the cache lookup when the BN version moved."""
         self._graphs.clear()
-        ops.release_retired_scratch()
+        if not any(t._graphs for t in _TRAINERS):
+            # retired finalize-scratch blocks are shared by every graph of the process: freed only when none is left
+            ops.release_retired_scratch()
         if torch.cuda.is_available():
-            torch.cuda.empty_cache()         # hand the dropped graphs' private pools back to the device
+            # hand the dropped graphs' private pools (all activations of a step per captured shape) back to the device.  This
+            # synchronises the device -- at a long-cycle switch, i.e. 13 times over the whole schedule (every rank switches
+            # at the same step: the sampler is deterministic in the step counter, cycle_batch_sampler.py:76-93)
+            torch.cuda.empty_cache()
 
     def _capture(self, x, y):
         sx, sy = x.clone(), y.clone()
