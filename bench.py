@@ -192,16 +192,30 @@ def _cpu_model():
     return "unknown"
 
 
+def _cpu_share():
+    """Cores this process may really use: the cgroup CPU quota when there is one (the GPU box gives one GPU a 16-core share
+    of a 256-thread host, and neither os.cpu_count() nor the affinity mask shows it), else the affinity mask; capped at 16,
+    the share the pool documents for one GPU."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(T, H, sample_B=2, budget_s=10.0, min_steps=3, max_steps=8):
     """CPU oracle (stock-PyTorch restatement of the reference, oracle/x3d_oracle.py) on the host cores: fwd+bwd of X3D-M on a
-    B = 2 sample of the headline clip shape, at ALL cores of this process's affinity mask and at 8 threads (SURVEY.md 8(d):
+    B = 2 sample of the headline clip shape, at ALL cores of this process's CPU share (_cpu_share) and at 8 threads (SURVEY.md 8(d):
     the 8-thread figure ties back to BASELINE.md's measurement of the reference itself in the 8-core build container)."""
     from oracle import x3d_oracle as xo
     from x3dhip import synthetic
-    try:
-        avail = len(os.sched_getaffinity(0))        # the GPU box gives one GPU a CPU share; os.cpu_count() is the whole host
-    except Exception:
-        avail = os.cpu_count() or 1
+    avail = _cpu_share()
     sd = synthetic.procedural_state_dict(xo.state_template("M", 400, 1), 0)
     x = synthetic.synthetic_clips(sample_B, T, H, H)
     y = synthetic.synthetic_labels(sample_B)
@@ -215,6 +229,7 @@ def cpu_baseline(T, H, sample_B=2, budget_s=10.0, min_steps=3, max_steps=8):
             t0 = time.time()
             xo.train_step_grads(x, y, sd, "M", 1)
             ts.append(time.time() - t0)
+            print("[bench] cpu baseline step %.2f s (%d threads)" % (ts[-1], threads), file=sys.stderr, flush=True)
         return sorted(ts)[len(ts) // 2], len(ts)
 
     t_all, n_all = timed(avail)

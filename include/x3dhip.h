@@ -57,6 +57,9 @@ const char* x3d_last_error(void);
 /* measurement aid: name of the kernel template (e.g. "pw6_kernel", "dw_bwd_kernel") the last pointwise / channelwise entry
  * point called from this thread launched -- the names a rocprofv3 --kernel-trace summary prints (bench.py groups by it) */
 const char* x3d_last_kernel(void);
+/* debug aid (tests): one launch that fills the LDS of every CU with a NaN pattern, so that a kernel which consumes an LDS
+ * word it never wrote produces a NaN instead of a plausible value; `sink`: any device buffer of >= 4 bytes (never written) */
+int x3d_debug_poison_lds(void* sink, void* stream);
 
 /* Tuning / A-B options (ABI 6).  The reference has no counterpart (its only knobs are the module constants of
  * train_x3d_kinetics_multigrid.py:49-61); these select between kernels of this library that compute the same function.

@@ -116,6 +116,60 @@ def test_train_step_is_bitwise_reproducible_under_poisoned_allocations(golden_di
         assert not bad, "poison=%s dirty=%s: %d tensors differ, first %s" % (poison, dirty, len(bad), bad[:8])
 
 
+@pytest.mark.parametrize("case", ["train_M_2x4x158_s2", "train_M_8x4x64_s2"])
+def test_train_step_is_bitwise_reproducible_with_poisoned_lds(golden_dir, case):
+    """LDS is not cleared between kernels.  The same step twice: as is, and with a kernel that fills the LDS of every CU with
+    NaN launched in front of EVERY library launch (x3d_debug_poison_lds).  A kernel that consumes an LDS word it did not
+    write -- a padding row of a staged tile, a statistics slot of an idle wave -- would turn into NaN (or change) in the
+    second run; logits and all 316 gradients must be bitwise equal."""
+    import ctypes
+    from x3dhip import _lib
+    dev = _dev()
+    g = _golden(golden_dir, case)
+    B, T, H, S = [int(v) for v in g["shape"]]
+    x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1])).to(dev)
+    y = synthetic.synthetic_labels(B, seed=int(g["seed"][1])).to(dev)
+    h = _lib.lib()
+    sink = torch.zeros(16, dtype=torch.int32, device=dev)
+    launching = [n for n, (res, args) in _lib.SIGNATURES.items()
+                 if res is ctypes.c_int and args and args[-1] is ctypes.c_void_p and n != "x3d_debug_poison_lds"]
+    assert "x3d_pw_fwd" in launching and "x3d_dw333_bwd" in launching and "x3d_get_option" not in launching
+    count = [0]
+
+    def run(poison_lds):
+        if poison_lds:
+            for n in launching:
+                real = getattr(h, n)
+
+                def wrapper(*a, _real=real):
+                    _lib.check(h.x3d_debug_poison_lds(sink.data_ptr(), _lib.stream()))
+                    count[0] += 1
+                    return _real(*a)
+                setattr(h, n, wrapper)              # instance attribute shadows the CDLL's cached function object
+        try:
+            net = _build(case.split("_")[1], S, dev, int(g["seed"][0]))
+            net.train(True)
+            logits = net(x)
+            loss = torch.nn.CrossEntropyLoss()(logits, y)
+            loss.backward()
+            torch.cuda.synchronize()
+            return [logits.detach().clone()] + [p.grad.detach().clone() for p in net.parameters()], \
+                [k for k, _ in net.named_parameters()]
+        finally:
+            if poison_lds:
+                for n in launching:
+                    delattr(h, n)
+                    fn = getattr(h, n)              # re-created by ctypes: restore its prototype
+                    fn.restype, fn.argtypes = _lib.SIGNATURES[n]
+
+    ref, names = run(False)
+    cur, _ = run(True)
+    assert count[0] > 300, count                     # the poison really ran between the launches of the step
+    assert all(bool(torch.isfinite(t).all()) for t in cur)
+    bad = [(["logits"] + names)[i] for i, (a, b) in enumerate(zip(ref, cur)) if not torch.equal(a, b)]
+    assert not bad, "%d tensors differ with poisoned LDS, first %s" % (len(bad), bad[:8])
+
+
 def test_loc_head_vs_reference_golden(golden_dir):
     """task='loc' (x3d.py:240-241,340-343): per-frame logits [B, C, T], pooling over (H, W) only; forward, backward
     (same label on every frame) and eval against the reference's golden."""

@@ -111,3 +111,37 @@ extern "C" int x3d_reset_options(void) {
 
 extern "C" int x3d_option_count(void) { return X3D_OPT_COUNT; }
 extern "C" const char* x3d_option_name(int index) { return (index >= 0 && index < X3D_OPT_COUNT) ? kOpts[index].name : nullptr; }
+
+
+// ---------------------------------------------------------------------------------------
+// Debug aid: fill the LDS of (very likely) every CU with a NaN pattern.  LDS is not cleared between kernels: a kernel that
+// consumes an LDS word it did not write sees whatever the previous workgroup on that CU left there.  Interleaved between the
+// launches of a step (tests/test_model_gpu.py), this turns such a read into a NaN in a named tensor instead of a
+// plausible-looking wrong value.  0x7FC07FC0 is a NaN as fp32, as a bf16 pair and (doubled) as fp64.
+// ---------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(1024) void poison_lds_kernel(int words, unsigned* sink) {
+    extern __shared__ unsigned lds_poison[];
+    for (int i = threadIdx.x; i < words; i += 1024) lds_poison[i] = 0x7FC07FC0u;
+    __syncthreads();
+    // keep the stores alive and the workgroup resident for a moment so that the grid spreads over all CUs
+    unsigned acc = 0;
+    for (int rep = 0; rep < 8; ++rep)
+        for (int i = threadIdx.x; i < words; i += 1024) acc += lds_poison[(i + rep) % words];
+    if (acc == 0x12345u) sink[0] = acc;        // never true for the pattern above
+}
+}  // namespace
+
+extern "C" int x3d_debug_poison_lds(void* sink, void* stream) {
+    X3D_CHECK_ARG(sink != nullptr);
+    const int bytes = 160 * 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr_done = true;
+    }
+    // one workgroup fills a CU's whole LDS; 4 waves of workgroups per CU: every CU gets at least one with near certainty
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(1024), bytes, (hipStream_t)stream, bytes / 4, (unsigned*)sink);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}

@@ -29,6 +29,7 @@ SIGNATURES = {
     "x3d_clip_preprocess": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "x3d_last_error": (ctypes.c_char_p, []),
     "x3d_last_kernel": (ctypes.c_char_p, []),
+    "x3d_debug_poison_lds": (_I, [_P, _P]),
     "x3d_set_option": (_I, [ctypes.c_char_p, _I]),
     "x3d_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "x3d_reset_options": (_I, []),
