@@ -170,6 +170,46 @@ def _pw_bwd(case, btol):
         assert _rel(out, F.conv_transpose3d(dY, w.view(Co, Ci, 1, 1, 1))) < btol
 
 
+@pytest.mark.parametrize("case", [(2, 216, 96, 4, 10, 10), (2, 96, 216, 4, 14, 14), (2, 432, 192, 4, 5, 5), (8, 192, 432, 4, 7, 7),
+                                  (4, 54, 24, 4, 28, 28), (4, 24, 54, 4, 28, 28), (2, 108, 48, 8, 14, 14)])
+def test_three_term_backward_is_as_accurate_as_the_fp32_mfma_kernels(case):
+    """"fp32 level" made concrete: on the same inputs, the error of the default (three bf16 terms, six products) backward
+    kernels against the fp64 oracle is no larger than that of the exact fp32-MFMA kernels (options dgrad_f32 / wgrad_f32)
+    against the same oracle -- both are fp32-accumulation noise (a few 1e-7); the two-term form is ~30x further away."""
+    from x3dhip import _lib, ops
+    dev = _dev()
+    N, Ci, Co, T, H, W = case
+    x = _g(N, Ci, T, H, W, seed=1)
+    w = _g(Co, Ci, seed=2) / np.sqrt(Ci)
+    g = _g(N, Co, T, H, W, seed=5)
+    a = _g(N, Co, T, H, W, seed=6)
+    cb = torch.stack([1 + 0.1 * _g(N, Co, seed=7), 0.1 * _g(N, Co, seed=8), 0.05 * _g(N, Co, seed=9)], -1)
+    dY = cb[..., 0, None, None, None] * g + cb[..., 1, None, None, None] * a + cb[..., 2, None, None, None]
+    din_ref = F.conv_transpose3d(dY, w.view(Co, Ci, 1, 1, 1))
+    dw_ref = torch.einsum("nopqr,nipqr->oi", dY, x)
+    to = lambda t: t.float().contiguous().to(dev)
+    wpt = ops.pw_pack(to(w), transposed=True)
+
+    def errs(**opts):
+        with _lib.options(**opts):
+            dx, _ = ops.pw_bwd_data(to(g), to(a), to(cb), to(w), wpt=wpt)
+            dw = ops.pw_bwd_weight(to(g), to(a), to(cb), to(x), (Co, Ci))
+            out = [_rel(dx, din_ref), _rel(dw, dw_ref)]
+            if ops.pw_bwd_fused_ok(Ci, Co, T * H * W):
+                dxf, _, dwf = ops.pw_bwd_fused(to(g), to(a), to(cb), (Co, Ci), wpt, to(x), mode=0)
+                out += [_rel(dxf, din_ref), _rel(dwf, dw_ref)]
+            return out
+    e3, ef, e2 = errs(), errs(dgrad_f32=1, wgrad_f32=1), errs(bwd_terms=2)
+    print("\n[%s] vs fp64: 3-term %s | fp32 MFMA %s | 2-term %s" % (case, ["%.1e" % v for v in e3], ["%.1e" % v for v in ef], ["%.1e" % v for v in e2]))
+    for i in range(2):
+        assert e3[i] <= 1.5 * ef[i] + 2e-7, (i, e3, ef)
+    assert e2[1] > 5 * e3[1], (e2, e3)                 # (the option really changes the weight-gradient kernel ...
+    if Co >= 64 and Ci >= 96:
+        assert e2[0] > 5 * e3[0], (e2, e3)             #  ... and the data-gradient kernel of the large-channel layers)
+    for v in e3:
+        assert v < 1e-6
+
+
 @pytest.mark.parametrize("terms", [3, 2])
 @pytest.mark.parametrize("case", [c for c in PW_CASES if c[6] == 1])
 def test_pw_bwd_data_res(case, terms):
