@@ -89,6 +89,17 @@ def test_pw_fwd_mx(case):
     y0, p0 = ops.pw_fwd(x, w, pre=pre, pre_act=act, wp=wp)
     y1, p1 = ops.pw_fwd(x.to(BF) if xb else x, w, pre=pre, pre_act=act, wp=wp, out_dtype=BF if yb else torch.float32)
     assert y1.dtype == (BF if yb else torch.float32)
+    # directly against the fp64 oracle on the same (bf16-representable) inputs, not only through the fp32 build: fp32
+    # arithmetic error for an fp32 output, one RNE rounding (2^-9 relative per element) on top for a bf16 output
+    from oracle import x3d_oracle as xo
+    xd = x.double().cpu()
+    if act:
+        sd = pre.double().cpu()[..., 0, None, None, None] * xd + pre.double().cpu()[..., 1, None, None, None]
+        xd = torch.relu(sd) if act == 1 else sd * torch.sigmoid(sd)
+    y_ref = xo.pw(xd, w.double().cpu().view(Co, Ci, 1, 1, 1), 1)
+    assert _rel(y1.float().cpu(), y_ref) < (3e-3 if yb else 2e-5)
+    if yb:
+        assert bool(((y1.float().cpu().double() - y_ref).abs() <= y_ref.abs() * 2.0 ** -8 + 1e-5).all())
     if Ci >= 64 and Co >= 96 and (T * H * W) % 4 != 0:
         # the fp32 default for this shape is the LDS-tiled kernel, the mixed mode streams: another summation order
         assert _rel(y1.float(), y0) < (3e-3 if yb else 2e-5)
@@ -264,6 +275,13 @@ def test_dw333_mx(case):
     y1, p1 = ops.dw333_fwd(x.to(BF), w, stride=s, pre=pre, pre_act=1)
     assert y1.dtype == BF and _same(y1, y0.to(BF))
     _stats_of(p1, y1, y1)
+    # directly against the fp64 oracle on the same bf16-representable input: one RNE rounding of the output on top of fp32
+    from oracle import x3d_oracle as xo
+    pd_ = pre.double().cpu()
+    hin = torch.relu(pd_[..., 0, None, None, None] * x.double().cpu() + pd_[..., 1, None, None, None])
+    y_ref = xo.dw333(hin, w.double().cpu(), s)
+    assert _rel(y1.float().cpu(), y_ref) < 3e-3
+    assert bool(((y1.float().cpu().double() - y_ref).abs() <= y_ref.abs() * 2.0 ** -8 + 1e-5).all())
     # training form (producer BN finalize in the prologue)
     sp = torch.rand(N, C, 3, 2, device=dev) + 0.5
     sp[..., 1] += 4.0

@@ -324,6 +324,37 @@ def test_graph_cache_released_at_long_cycle_switches():
     assert len(tr._graphs) == 1
 
 
+def test_static_inputs_feed_the_graph_without_a_copy():
+    """Trainer.static_inputs: batches written straight into the captured graph's input tensors train exactly like batches
+    that are copied in (the path a device-side input pipeline and bench.py use)."""
+    import x3d as resnet_x3d
+    from x3dhip.trainer import Trainer
+    dev = _dev()
+    sd = synthetic.procedural_state_dict(xo.state_template("M", 400, 1), 0)
+    batches = [(synthetic.synthetic_clips(4, 2, 32, 32, seed=s).to(dev), synthetic.synthetic_labels(4, seed=s).to(dev)) for s in (1, 2, 3)]
+
+    def run(static):
+        m = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=1)
+        m.load_state_dict(sd)
+        m.to(dev).train(True)
+        tr = Trainer(m, lr=0.05, use_graph=True)
+        assert tr.static_inputs(batches[0][0].shape) is None
+        losses = []
+        for x, y in batches:
+            st = tr.static_inputs(x.shape) if static else None
+            if st is not None:
+                st[0].copy_(x)              # what an input pipeline does: produce the batch in place
+                st[1].copy_(y)
+                x, y = st
+            loss, _ = tr.train_step(x, y)
+            losses.append(float(loss))
+        return losses, tr.fp.flat.clone()
+
+    l0, w0 = run(False)
+    l1, w1 = run(True)
+    assert l0 == l1 and torch.equal(w0, w1)
+
+
 def test_retired_scratch_outlives_every_captured_graph_of_the_process():
     """Captured graphs replay into the process-wide finalize scratch by raw pointer.  A block that was outgrown is retired,
     and may be released only when NO trainer of the process holds a graph: another trainer's invalidate_graphs() must not

@@ -212,6 +212,25 @@ class Trainer:
         self._sgd()                          # outside any graph: lr / first-step flag are host values
         return loss, logits
 
+    @staticmethod
+    def _feed(ent, x, y):
+        """Hand a batch to a captured graph: copied into the graph's static input tensors -- unless the caller already wrote
+        it there (`static_inputs`): a device-side input pipeline (kinetics_multigrid.DeviceVideoKinetics(out=...)) or a
+        benchmark that keeps its synthetic clips resident fills the static buffers directly and no copy is made."""
+        if x.data_ptr() != ent["x"].data_ptr():
+            ent["x"].copy_(x)
+        if y.data_ptr() != ent["y"].data_ptr():
+            ent["y"].copy_(y)
+
+    def static_inputs(self, x_shape):
+        """(clips, labels) tensors the captured graph(s) of this clip shape read, or None before the first step of that
+        shape: write the next batch into them and pass them to train_step to skip the input copy."""
+        shp = tuple(x_shape)
+        for key, ent in self._graphs.items():
+            if (key[0] == "split" and key[1] == shp) or key[0] == shp:
+                return ent["x"], ent["y"]
+        return None
+
     MAX_GRAPHS = 6      # shapes of one long cycle: 2-3 (cycle_batch_sampler.py:98-111); each graph pins its activations
 
     def _lookup(self, key):
@@ -257,8 +276,7 @@ class Trainer:
         if ent is None:
             ent = self._capture(x, y)
             self._store(key, ent)
-        ent["x"].copy_(x)
-        ent["y"].copy_(y)
+        self._feed(ent, x, y)
         ent["fb"].replay()
         self.model._pending_tracked += 1     # the replayed forward advanced every split-BN once
         return ent["loss"], ent["logits"]
@@ -317,8 +335,7 @@ class Trainer:
         if ent is None:
             ent = self._capture_split(x, y)
             self._store(key, ent)
-        ent["x"].copy_(x)
-        ent["y"].copy_(y)
+        self._feed(ent, x, y)
         ent["ga"].replay()
         self.reducer.start_bucket(0)          # head + layer4 + layer3 gradients: on the wire while graph B runs
         ent["gb"].replay()
