@@ -27,3 +27,8 @@ def test_two_rank_bench_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4
     assert d["value"] > 0 and d["unit"] == "clips/s"
+    # the data-parallel section the multi-GPU scaling record explains itself with
+    dp = d["data_parallel"]
+    assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and len(dp["buckets_bytes"]) == 2
+    assert len(dp["allreduce_ms_per_bucket_standalone"]) == 2 and all(t > 0 for t in dp["allreduce_ms_per_bucket_standalone"])
+    assert sum(dp["buckets_bytes"]) == 4 * 3794322        # the flat fp32 gradient of X3D-M (15.18 MB)
