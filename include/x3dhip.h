@@ -68,7 +68,8 @@ int x3d_debug_poison_lds(void* sink, void* stream);
  * of the same meaning (X3D_FB_GRID, X3D_DGRAD_F32, ...: DESIGN.md section 7).  Names: x3d_option_name(0 .. x3d_option_count()-1):
  *   fb_grid, pw_pgrid, pw_nt4_min, pw_no_persist, dw_th, dw_balance, dw_no_v2, no_pw6, no_pw7, no_pwfs, dgrad_f32,
  *   wgrad_f32, bwd_terms (3 = fp32-level three-term bf16 split of the backward GEMM operands, 2 = two-term, ~2^-16),
- *   no_wgrad4, wg_cpw, wg_cap, stem_wg_cap.
+ *   no_wgrad4, wg_cpw, wg_cap, stem_wg_cap, dw_tsplit_wgs (channelwise launches of at most this many workgroups cut the T
+ *   march into two segments; 0 = never).
  * Unknown name or out-of-range value: X3D_EINVAL. */
 int x3d_set_option(const char* name, int value);
 int x3d_get_option(const char* name, int* value);
@@ -203,7 +204,7 @@ int x3d_reduce_partials_batch(const float* const* partials, float* const* outs, 
  * Channelwise 3x3x3 convolution (conv3x3x3 x3d.py:87-95, Bottleneck.conv2 :114,150):
  * groups=C, pad 1, stride (1,s,s), no bias.  HBM-bound; LDS-staged T-marching stencil.
  * ---------------------------------------------------------------------------------- */
-int x3d_dw_tiles(int N, int C, int H_out, int W_out);  /* spatial tiles per (n,c) used for `partial` (same N, C as the launch) */
+int x3d_dw_tiles(int N, int C, int T, int H_out, int W_out);  /* slots per (n,c) of `partial`: row tiles x T segments (same N, C, T as the launch; ABI 6) */
 
 /* y = dw333(relu(pre*x+pre) zero-padded).  partial: float[N][C][tiles][2] {sum y, sum y^2}.
  * pre_act of the channelwise entries: X3D_ACT_RELU or X3D_ACT_NONE only (x3d.py:147-150: ReLU precedes conv2);
@@ -227,9 +228,9 @@ int x3d_dw333_fwd_stats(const void* x, const float* w, void* y, int N, int C, in
  *   dY = cb0*g + cb1*a + cb2 (g,a at output resolution [N,C,T,Ho,Wo])
  *   hin = act(pre*x+pre)  (x raw [N,C,T,H,W])
  *   out = dw333^T(dY) * act'(pre*x+pre)           -> [N,C,T,H,W]
- *   dW[c,kt,kh,kw] partials: float[N][x3d_dw_bwd_tiles(N,C,H,W,s)][C][27] (group-sum over the first two dims)
- *   partial: float[N][C][x3d_dw_bwd_tiles(N,C,H,W,s)][2] {sum out, sum out*x}  */
-int x3d_dw_bwd_tiles(int N, int C, int H, int W, int strideHW);
+ *   dW[c,kt,kh,kw] partials: float[N][x3d_dw_bwd_tiles(N,C,T,H,W,s)][C][27] (group-sum over the first two dims)
+ *   partial: float[N][C][x3d_dw_bwd_tiles(N,C,T,H,W,s)][2] {sum out, sum out*x}  */
+int x3d_dw_bwd_tiles(int N, int C, int T, int H, int W, int strideHW);   /* (ABI 6: takes T, as x3d_dw_tiles) */
 int x3d_dw333_bwd(const void* g, const void* a, const float* cb, const float* w,
                   const void* x, const float* pre, int pre_act,
                   void* out, float* wpartial, float* partial,

@@ -34,7 +34,8 @@ def test_library_loads_and_exports_every_symbol():
     assert h.x3d_pw_tiles(1, 24, 54, 1000, 1) == 16 and h.x3d_pw_tiles(64, 24, 54, 100000, 1) == 391
     assert h.x3d_pw_tiles(8, 216, 96, 3136, 1) == 49
     assert h.x3d_ew_tiles(4097) == 3
-    assert h.x3d_dw_tiles(8, 54, 56, 56) >= 1
+    assert h.x3d_dw_tiles(8, 54, 16, 56, 56) == 4                     # 4 row tiles of 14 rows, one T segment
+    assert h.x3d_dw_tiles(8, 432, 16, 7, 7) == 2                      # 216 workgroups < 256 CUs: two T segments
     assert h.x3d_last_error() is not None
 
 
@@ -45,7 +46,7 @@ def test_option_table_set_get_reset():
         import __graft_entry__ as ge
         ge.build()
     names = _lib.option_names()
-    assert {"fb_grid", "bwd_terms", "dgrad_f32", "wgrad_f32", "dw_th", "no_pw6", "no_pw7", "no_pwfs"} <= set(names)
+    assert {"fb_grid", "bwd_terms", "dgrad_f32", "wgrad_f32", "dw_th", "no_pw6", "no_pw7", "no_pwfs", "dw_tsplit_wgs"} <= set(names)
     assert _lib.get_option("bwd_terms") == 3 and _lib.get_option("fb_grid") == 512
     h = _lib.lib()
     assert h.x3d_pw_bwd_fused_groups(2, 24964) == 512

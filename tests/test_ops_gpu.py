@@ -443,6 +443,35 @@ def test_dw333_fwd_bwd(case):
     assert _rel(st[..., 1], (out_ref * x).sum(dim=(2, 3, 4))) < 1e-4
 
 
+@pytest.mark.parametrize("case", [(8, 432, 16, 7, 7, 1), (2, 10, 16, 14, 14, 1), (2, 3, 8, 28, 28, 2), (1, 7, 9, 7, 7, 1),
+                                  (2, 40, 11, 5, 5, 2), (1, 2, 8, 40, 56, 1)])
+def test_dw333_t_segments_equal_the_single_march(case):
+    """Launches with fewer workgroups than CUs cut the T march into two segments (option dw_tsplit_wgs; the 7 x 7 planes of
+    stage 4 at the base shape).  Every output voxel is computed by the same arithmetic either way: y and dx BITWISE equal to
+    the unsplit launch (dw_tsplit_wgs = 0); statistics and weight gradients are sums over more partials: 1e-6."""
+    from x3dhip import _lib, ops
+    dev = _dev()
+    N, C, T, H, W, s = case
+    Ho, Wo = xo.out_hw(H, s), xo.out_hw(W, s)
+    to = lambda t: t.float().contiguous().to(dev)
+    x, w = to(_g(N, C, T, H, W, seed=1)), to(_g(C, 1, 3, 3, 3, seed=2) / 3)
+    pre = to(torch.stack([1 + 0.2 * _g(N, C, seed=3), 0.3 * _g(N, C, seed=4)], -1))
+    g, a = to(_g(N, C, T, Ho, Wo, seed=5)), to(_g(N, C, T, Ho, Wo, seed=6))
+    cb = to(torch.stack([1 + 0.1 * _g(N, C, seed=7), 0.1 * _g(N, C, seed=8), 0.05 * _g(N, C, seed=9)], -1))
+
+    def run(wgs):
+        with _lib.options(dw_tsplit_wgs=wgs):
+            y, p = ops.dw333_fwd(x, w, stride=s, pre=pre, pre_act=1)
+            dx, dw, bp = ops.dw333_bwd(g, a, cb, w, x, stride=s, pre=pre, pre_act=1)
+            return y, p, dx, dw, bp
+    y0, p0, dx0, dw0, bp0 = run(0)
+    y1, p1, dx1, dw1, bp1 = run(1 << 20)                     # always split (T >= 8)
+    assert p1.shape[2] == 2 * p0.shape[2] and bp1.shape[2] == 2 * bp0.shape[2]
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    assert _rel(p1.double().sum(2), p0.double().sum(2)) < 1e-6 and _rel(bp1.double().sum(2), bp0.double().sum(2)) < 1e-6
+    assert _rel(dw1, dw0) < 1e-6
+
+
 @pytest.mark.parametrize("case", DW_CASES)
 @pytest.mark.parametrize("S", [1, 2])
 def test_dw333_fwd_stats_equals_finalize_then_conv(case, S):

@@ -30,7 +30,11 @@ struct DwGeom {
     int N, C, T, H, W, Ho, Wo, stride;
     int TH, groups, cpb, ipc;     // rows per tile (of the thread-mapped grid), float4 groups per row, channels per block, items per channel
     int IH, WP, slot;             // staged rows per plane, padded row length, floats per slot (cpb*IH*WP)
-    int tiles;
+    int tiles;                    // row tiles of a plane
+    // T segments (round 3): when a launch has fewer workgroups than the chip has CUs (the 7 x 7 planes of stage 4: 216),
+    // the T march is cut into `tsegs` segments of `tlen` steps, one workgroup each (one extra staged plane per later segment);
+    // statistics / weight-gradient slots are indexed by blockIdx.x = seg * tiles + tile: tiles * tsegs slots per (n, c)
+    int tsegs, tlen;
 };
 
 // thread-mapped grid = OUTPUT grid for forward, INPUT grid for backward
@@ -63,6 +67,9 @@ static DwGeom make_geom(int N, int C, int T, int H, int W, int stride, bool back
     if (!backward) g.IH = (th - 1) * stride + 3;
     else g.IH = stride == 1 ? th + 2 : th / 2 + 2;
     g.slot = cpb * g.IH * g.WP;
+    g.tsegs = 1; g.tlen = T;
+    const long long wgs = (long long)g.tiles * cdiv(C, cpb) * N;
+    if (T >= 8 && wgs <= (long long)x3d_opt(X3D_OPT_DW_TSPLIT_WGS)) { g.tsegs = 2; g.tlen = cdiv(T, 2); }
     return g;
 }
 
@@ -226,7 +233,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     constexpr int NV = (STRIDE == 1) ? 18 : 27;          // window values per plane
     const DwGeom& g = A.g;
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x, c0 = blockIdx.y * g.cpb, n = blockIdx.z;
+    const int slot_id = blockIdx.x;                     // seg * tiles + tile: statistics slot of this workgroup
+    const int tile = slot_id % g.tiles, seg = slot_id / g.tiles, c0 = blockIdx.y * g.cpb, n = blockIdx.z;
+    const int t0 = seg * g.tlen, t1 = min(g.T, t0 + g.tlen);      // this workgroup's output planes [t0, t1)
     const int ho0 = tile * g.TH;
     const int h_in0 = dw_tile_row0(tile, g.TH, STRIDE, false);
     float* ring = lds;                                  // 2 slots
@@ -253,8 +262,10 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     const int plane = g.H * g.W;
 
     float4 reg[NCH], reg1[NCH];
-    fetch4<NCH, VW, MX>(xb, ch, 0, true, reg);          // need addresses only: in flight during the statistics below
-    fetch4<NCH, VW, MX>(xb, ch, plane, g.T > 1, reg1);  // (planes 0 and 1 together: one round trip less)
+    fetch4<NCH, VW, MX>(xb, ch, t0 * plane, true, reg);              // need addresses only: in flight during the statistics below
+    fetch4<NCH, VW, MX>(xb, ch, (t0 + 1) * plane, t0 + 1 < g.T, reg1);  // (two planes together: one round trip less)
+    float4 regm[NCH];                                                 // a later T segment also needs plane t0 - 1
+    if (t0 > 0) fetch4<NCH, VW, MX>(xb, ch, (t0 - 1) * plane, true, regm);
     if (A.sp != nullptr) {
         // BN finalize of this workgroup's channels for sample n's split (x3d.py:47-58): fp64 sums over N/S samples x
         // stiles partial pairs in a fixed order (identical in every workgroup of a (split, channel)); the tile-0
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
             const float shv = (float)((double)A.beta[cg] - mean * (double)A.gamma[cg] * invstd);
             lcoef[tid * 2] = scv;
             lcoef[tid * 2 + 1] = shv;
-            if (tile == 0 && c0 + tid < g.C) {
+            if (slot_id == 0 && c0 + tid < g.C) {
                 A.coef_out[((size_t)n * g.C + cg) * 2] = scv;
                 A.coef_out[((size_t)n * g.C + cg) * 2 + 1] = shv;
                 if (n == j) {
@@ -330,8 +341,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
         __syncthreads();
     }
     const float act_lo = dw_act_lo(A.pre_act);
+    // ring slot of plane t: (t - t0) & 1
     store_act<NCH, VW>(ring, ch, true, act_lo, reg);
-    store_act<NCH, VW>(ring + g.slot, ch, g.T > 1, act_lo, reg1);
+    store_act<NCH, VW>(ring + g.slot, ch, t0 + 1 < g.T, act_lo, reg1);
     __syncthreads();
 
     // LDS offset of this thread's first window element
@@ -374,10 +386,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     // fresh store; the store's ack then hides under the next step's stencil.
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
         if (t == 5) DTR(2);
-        fetch4<NCH, VW, MX>(xb, ch, (t + 2) * plane, t + 2 < g.T, reg);    // in flight during the stencil
+        const bool more = t + 2 < g.T && t + 2 <= t1;                  // plane t + 2 feeds output t + 1 < t1
+        fetch4<NCH, VW, MX>(xb, ch, (t + 2) * plane, more, reg);       // in flight during the stencil
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
-            read_plane(ring + (size_t)((t + 1) & 1) * g.slot, wc);
+            read_plane(ring + (size_t)((t + 1 - t0) & 1) * g.slot, wc);
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
                 const float(&v)[NV] = kt == 0 ? wa : (kt == 1 ? wb : wc);
@@ -404,8 +417,8 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
             s2 = fmaf(o[0], o[0], fmaf(o[1], o[1], fmaf(o[2], o[2], fmaf(o[3], o[3], s2))));
         }
         if (t == 5) DTR(3);
-        // slot t&1 held plane t, last read one barrier ago -> free for plane t+2
-        store_act<NCH, VW>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, act_lo, reg);
+        // the slot of plane t, last read one barrier ago -> free for plane t+2
+        store_act<NCH, VW>(ring + (size_t)((t - t0) & 1) * g.slot, ch, more, act_lo, reg);
         if (t == 5) DTR(4);
         if (valid) {
             float* py = A.y + ybase + (size_t)t * g.Ho * g.Wo;
@@ -440,13 +453,21 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     float w0[NV], w1[NV], w2[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { w0[i] = 0.f; w1[i] = 0.f; w2[i] = 0.f; }
-    if (valid) read_plane(ring, w1);                     // plane 0
-    __syncthreads();       // step 0 overwrites slot 0: every wave must have read plane 0 first
+    if (valid) read_plane(ring, w1);                     // plane t0
+    __syncthreads();       // the first step overwrites slot 0: every wave must have read plane t0 first
+    if (t0 > 0) {
+        // a later T segment: plane t0 - 1 is part of the first output's window -- staged through the free slot 0 (plane
+        // t0 + 1 sits in slot 1), read into the window, then slot 0 goes back to the march
+        store_act<NCH, VW>(ring, ch, true, act_lo, regm);
+        __syncthreads();
+        if (valid) read_plane(ring, w0);
+        __syncthreads();
+    }
     DTR(1);
-    for (int t = 0; t < g.T; t += 3) {
+    for (int t = t0; t < t1; t += 3) {
         step(t, w0, w1, w2);
-        if (t + 1 < g.T) step(t + 1, w1, w2, w0);
-        if (t + 2 < g.T) step(t + 2, w2, w0, w1);
+        if (t + 1 < t1) step(t + 1, w1, w2, w0);
+        if (t + 2 < t1) step(t + 2, w2, w0, w1);
     }
     DTR(6);
 
@@ -459,7 +480,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
             if (c0 + chn < g.C) {
                 float s = 0.f;
                 for (int i = 0; i < g.ipc; ++i) s += redbuf[(chn * g.ipc + i) * 2 + which];
-                A.partial[(((size_t)n * g.C + c0 + chn) * g.tiles + tile) * 2 + which] = s;
+                A.partial[(((size_t)n * g.C + c0 + chn) * (g.tiles * g.tsegs) + slot_id) * 2 + which] = s;
             }
         }
     }
@@ -519,7 +540,9 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     constexpr int NV = (STRIDE == 1) ? 18 : 6;           // window values per plane
     const DwGeom& g = A.geo;
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x, c0 = blockIdx.y * g.cpb, n = blockIdx.z;
+    const int slot_id = blockIdx.x;                               // seg * tiles + tile
+    const int tile = slot_id % g.tiles, seg = slot_id / g.tiles, c0 = blockIdx.y * g.cpb, n = blockIdx.z;
+    const int t0 = seg * g.tlen, t1 = min(g.T, t0 + g.tlen);      // this workgroup's planes [t0, t1)
     const int h0 = tile * g.TH;                                   // first input row of the tile
     const int ho_lo = dw_tile_row0(tile, g.TH, STRIDE, true);     // first staged output row
     float* ring = lds;
@@ -561,8 +584,13 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     const int plane_o = g.Ho * g.Wo;
 
     float4 rg[NCH], ra[NCH];
-    fetch4<NCH, VW, MX>(gb, ch, 0, true, rg);           // addresses only: in flight during the statistics below
-    fetch4<NCH, VW, MX>(ab, ch, 0, true, ra);
+    fetch4<NCH, VW, MX>(gb, ch, t0 * plane_o, true, rg);           // addresses only: in flight during the statistics below
+    fetch4<NCH, VW, MX>(ab, ch, t0 * plane_o, true, ra);
+    float4 rgm[NCH], ram[NCH];                                     // a later T segment also needs dY plane t0 - 1
+    if (t0 > 0) {
+        fetch4<NCH, VW, MX>(gb, ch, (t0 - 1) * plane_o, true, rgm);
+        fetch4<NCH, VW, MX>(ab, ch, (t0 - 1) * plane_o, true, ram);
+    }
     if (A.cb == nullptr) {
         // BN backward finalize of this workgroup's channels (single split; x3d.py:47-58 backward): fp64 sums over all
         // samples x stiles partial pairs in a fixed order (identical in every workgroup of a channel); the (tile 0,
@@ -608,7 +636,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             lcb[tid * 3] = (float)k;
             lcb[tid * 3 + 1] = (float)(-k * invstd * sgx / M);
             lcb[tid * 3 + 2] = (float)(-k * sg / M + k * invstd * mean * sgx / M);
-            if (tile == 0 && n == 0 && c0 + tid < g.C) {
+            if (slot_id == 0 && n == 0 && c0 + tid < g.C) {
                 A.dgamma[cg] = (float)sgx;
                 A.dbeta[cg] = (float)sg;
             }
@@ -626,11 +654,11 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         __syncthreads();
     }
     {
-        float4 rg1[NCH], ra1[NCH];                       // plane 1 requested before plane 0 is staged: one round trip less
-        fetch4<NCH, VW, MX>(gb, ch, plane_o, g.T > 1, rg1);
-        fetch4<NCH, VW, MX>(ab, ch, plane_o, g.T > 1, ra1);
+        float4 rg1[NCH], ra1[NCH];                       // the second plane requested before the first is staged: one round trip less
+        fetch4<NCH, VW, MX>(gb, ch, (t0 + 1) * plane_o, t0 + 1 < g.T, rg1);
+        fetch4<NCH, VW, MX>(ab, ch, (t0 + 1) * plane_o, t0 + 1 < g.T, ra1);
         store_dy<NCH, VW>(ring, ch, true, k0, k1, k2, rg, ra);
-        store_dy<NCH, VW>(ring + g.slot, ch, g.T > 1, k0, k1, k2, rg1, ra1);
+        store_dy<NCH, VW>(ring + g.slot, ch, t0 + 1 < g.T, k0, k1, k2, rg1, ra1);
     }
     __syncthreads();
 
@@ -711,18 +739,19 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             for (int i = 1; i < 4; ++i) xnext[i] = i < rem ? xnext[i] : 0.f;
         }
     };
-    load_x(0);
+    load_x(t0);
 
     // window planes (wa, wb, wc) = dY planes (t-1, t, t+1); time tap kt uses plane t+1-kt
     auto step = [&](int t, float (&wa)[NV], float (&wb)[NV], float (&wc)[NV]) {
         if (t == 5) DTR(2);
-        fetch4<NCH, VW, MX>(gb, ch, (t + 2) * plane_o, t + 2 < g.T, rg);
-        fetch4<NCH, VW, MX>(ab, ch, (t + 2) * plane_o, t + 2 < g.T, ra);
+        const bool more = t + 2 < g.T && t + 2 <= t1;                // dY plane t + 2 feeds the input plane t + 1 < t1
+        fetch4<NCH, VW, MX>(gb, ch, (t + 2) * plane_o, more, rg);
+        fetch4<NCH, VW, MX>(ab, ch, (t + 2) * plane_o, more, ra);
         float xv[4] = {xnext[0], xnext[1], xnext[2], xnext[3]};      // loaded one step ago, complete since the last LDS staging
         load_x(t + 1);                                               // next step's raw input, in flight during the stencil
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
-            read_plane(ring + (size_t)((t + 1) & 1) * g.slot, wc);
+            read_plane(ring + (size_t)((t + 1 - t0) & 1) * g.slot, wc);
             float hin[4], dact[4], d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -782,7 +811,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         }
         if (t == 5) DTR(3);
         // all loads of this step (dY plane t+2, x of step t+1) are consumed before the output store is issued
-        store_dy<NCH, VW>(ring + (size_t)(t & 1) * g.slot, ch, t + 2 < g.T, k0, k1, k2, rg, ra);
+        store_dy<NCH, VW>(ring + (size_t)((t - t0) & 1) * g.slot, ch, more, k0, k1, k2, rg, ra);
         if (t == 5) DTR(4);
         if (valid) {
             float* po = A.out + xbase + (size_t)t * g.H * g.W;
@@ -814,13 +843,19 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     float wv0[NV], wv1[NV], wv2[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { wv0[i] = 0.f; wv1[i] = 0.f; wv2[i] = 0.f; }
-    if (valid) read_plane(ring, wv1);                    // dY plane 0
-    __syncthreads();       // step 0 overwrites slot 0: every wave must have read plane 0 first
+    if (valid) read_plane(ring, wv1);                    // dY plane t0
+    __syncthreads();       // the first step overwrites slot 0: every wave must have read plane t0 first
+    if (t0 > 0) {          // a later T segment: dY plane t0 - 1 through the free slot 0 into the window (see dw_fwd_kernel)
+        store_dy<NCH, VW>(ring, ch, true, k0, k1, k2, rgm, ram);
+        __syncthreads();
+        if (valid) read_plane(ring, wv0);
+        __syncthreads();
+    }
     DTR(1);
-    for (int t = 0; t < g.T; t += 3) {
+    for (int t = t0; t < t1; t += 3) {
         step(t, wv0, wv1, wv2);
-        if (t + 1 < g.T) step(t + 1, wv1, wv2, wv0);
-        if (t + 2 < g.T) step(t + 2, wv2, wv0, wv1);
+        if (t + 1 < t1) step(t + 1, wv1, wv2, wv0);
+        if (t + 2 < t1) step(t + 2, wv2, wv0, wv1);
     }
     DTR(6);
 
@@ -841,8 +876,9 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
             for (; i + 3 < g.ipc; i += 4) { s0 += rp[i]; s1_ += rp[i + 1]; s2_ += rp[i + 2]; s3 += rp[i + 3]; }
             for (; i < g.ipc; ++i) s0 += rp[i];
             const float s = (s0 + s1_) + (s2_ + s3);
-            const size_t row_id = ((size_t)n * g.C + c0 + chn) * g.tiles + tile;
-            if (k < 27) A.wpartial[(((size_t)n * g.tiles + tile) * g.C + c0 + chn) * 27 + k] = s;   // [N][tiles][C][27]
+            const int slots = g.tiles * g.tsegs;
+            const size_t row_id = ((size_t)n * g.C + c0 + chn) * slots + slot_id;
+            if (k < 27) A.wpartial[(((size_t)n * slots + slot_id) * g.C + c0 + chn) * 27 + k] = s;   // [N][tiles * tsegs][C][27]
             else if (A.partial != nullptr) A.partial[row_id * 2 + (k - 27)] = s;
         }
     }
@@ -876,19 +912,20 @@ static int nch_for(const DwGeom& g, bool backward) {
 
 // The tile height depends on N and C too (whole rounds of workgroups, make_geom): the queries take the same N, C as the
 // launch they size buffers for.
-extern "C" int x3d_dw_tiles(int N, int C, int H_out, int W_out) {
-    DwGeom g = make_geom(N, C, 1, H_out, W_out, 1, false);
-    return g.tiles;
+// statistics / weight-gradient slots per (n, c): row tiles x T segments of the launch with the same N, C, T
+extern "C" int x3d_dw_tiles(int N, int C, int T, int H_out, int W_out) {
+    DwGeom g = make_geom(N, C, T, H_out, W_out, 1, false);
+    return g.tiles * g.tsegs;
 }
 
-extern "C" int x3d_dw_bwd_tiles(int N, int C, int H, int W, int strideHW) {
-    DwGeom g1 = make_geom(N, C, 1, H, W, strideHW == 2 ? 2 : 1, true);
-    return g1.tiles;
+extern "C" int x3d_dw_bwd_tiles(int N, int C, int T, int H, int W, int strideHW) {
+    DwGeom g1 = make_geom(N, C, T, H, W, strideHW == 2 ? 2 : 1, true);
+    return g1.tiles * g1.tsegs;
 }
 
 template <typename K, typename ARGS>
 static int dw_launch(K kernel, const ARGS& args, const DwGeom& g, size_t ldsb, hipStream_t s) {
-    dim3 grid(g.tiles, cdiv(g.C, g.cpb), g.N), block(256);
+    dim3 grid(g.tiles * g.tsegs, cdiv(g.C, g.cpb), g.N), block(256);
     if (ldsb > 48 * 1024) {
         // raise the kernel's dynamic-LDS limit once per (kernel, size) -- not on every launch, so a
         // launch captured into a hipGraph performs no attribute call

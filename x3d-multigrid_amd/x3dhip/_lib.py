@@ -57,9 +57,9 @@ SIGNATURES = {
     "x3d_wgrad_job_bytes": (ctypes.c_size_t, []),
     "x3d_pw_bwd_weight_batch": (_I, [_P, _I, _P]),
     "x3d_reduce_partials_batch": (_I, [_P, _P, _P, _P, _I, _P]),
-    "x3d_dw_tiles": (_I, [_I, _I, _I, _I]),
+    "x3d_dw_tiles": (_I, [_I, _I, _I, _I, _I]),
     "x3d_dw333_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
-    "x3d_dw_bwd_tiles": (_I, [_I, _I, _I, _I, _I]),
+    "x3d_dw_bwd_tiles": (_I, [_I, _I, _I, _I, _I, _I]),
     "x3d_dw333_bwd_stats": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_dw333_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_stem133_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -306,7 +306,7 @@ def dw333_fwd(x, w, stride=1, pre=None, pre_act=ACT_RELU, want_stats=True, out=N
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
     y = out if out is not None else _f((N, C, T, Ho, Wo), x, x.dtype)
     if want_stats and partial is None:
-        partial = _f((N, C, L.x3d_dw_tiles(N, C, Ho, Wo), 2), x)
+        partial = _f((N, C, L.x3d_dw_tiles(N, C, T, Ho, Wo), 2), x)
     check(L.x3d_dw333_fwd(ptr(x), ptr(w), ptr(y), N, C, T, H, W, stride, ptr(pre), pre_act,
                           ptr(partial) if want_stats else None, (MX_X | MX_Y) if _bf(x) else 0, _lib.stream()))
     return y, (partial if want_stats else None)
@@ -321,7 +321,7 @@ def dw333_fwd_stats(x, w, spartial, S, count, gamma, beta, running_mean, running
     N, C, T, H, W = x.shape
     Ho, Wo = out_hw(H, stride), out_hw(W, stride)
     y = _f((N, C, T, Ho, Wo), x, x.dtype)
-    partial = _f((N, C, L.x3d_dw_tiles(N, C, Ho, Wo), 2), x)
+    partial = _f((N, C, L.x3d_dw_tiles(N, C, T, Ho, Wo), 2), x)
     coef = _f((N, C, 2), x)
     save = _f((2, S, C), x)
     check(L.x3d_dw333_fwd_stats(ptr(x), ptr(w), ptr(y), N, C, T, H, W, stride, ptr(spartial), spartial.shape[2], S, count,
@@ -342,7 +342,7 @@ def dw333_bwd(g, a, cb, w, x, stride=1, pre=None, pre_act=ACT_RELU, out=None, wp
     mx = (MX_GA | MX_X | MX_Y) if _bf(x) else 0
     L = _lib.lib()
     N, C, T, H, W = x.shape
-    tiles = L.x3d_dw_bwd_tiles(N, C, H, W, stride)
+    tiles = L.x3d_dw_bwd_tiles(N, C, T, H, W, stride)
     o = out if out is not None else _f(x.shape, x, x.dtype)
     if wpartial is None:
         wpartial = _f((N, tiles, C, 27), x)
