@@ -52,6 +52,8 @@ const OptDef kOpts[X3D_OPT_COUNT] = {
     /* X3D_OPT_WG_CAP         */ {"wg_cap", "X3D_WG_CAP", 256, 0},
     /* X3D_OPT_STEM_WG_CAP    */ {"stem_wg_cap", "X3D_STEM_WG_CAP", 512, 0},
     /* X3D_OPT_DW_TSPLIT_WGS  */ {"dw_tsplit_wgs", "X3D_DW_TSPLIT_WGS", 256, 0},
+    /* X3D_OPT_DW_CPB_MAX     */ {"dw_cpb_max", "X3D_DW_CPB_MAX", 16, 0},
+    /* X3D_OPT_PW6_MIN_M      */ {"pw6_min_m", "X3D_PW6_MIN_M", 96, 0},
 };
 std::atomic<int> g_opt[X3D_OPT_COUNT];
 std::once_flag g_opt_once;
@@ -73,8 +75,9 @@ bool opt_valid(int id, int v) {
     switch (id) {
         case X3D_OPT_FB_GRID: case X3D_OPT_PW_PGRID: case X3D_OPT_WG_CAP: case X3D_OPT_STEM_WG_CAP: return v >= 1 && v <= 65535;
         case X3D_OPT_PW_NT4_MIN: case X3D_OPT_DW_TSPLIT_WGS: return v >= 0;
-        case X3D_OPT_DW_TH: return v >= 1 && v <= 16;
+        case X3D_OPT_DW_TH: case X3D_OPT_DW_CPB_MAX: return v >= 1 && v <= 16;
         case X3D_OPT_WG_CPW: return v >= 1 && v <= 4096;
+        case X3D_OPT_PW6_MIN_M: return v >= 16 && v <= 4096;
         case X3D_OPT_BWD_TERMS: return v == 2 || v == 3;
         default: return v == 0 || v == 1;
     }

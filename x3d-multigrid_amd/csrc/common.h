@@ -31,6 +31,8 @@ enum X3DOpt {
     X3D_OPT_WG_CAP,           // weight gradient: workgroup cap per conv                                           256
     X3D_OPT_STEM_WG_CAP,      // stem weight gradient: workgroups                                                  512
     X3D_OPT_DW_TSPLIT_WGS,    // channelwise kernels: launches of at most this many workgroups split T in two      256 (0: never)
+    X3D_OPT_DW_CPB_MAX,       // channelwise kernels: maximum channels per workgroup                               16
+    X3D_OPT_PW6_MIN_M,        // whole-K forward kernel pw6: smallest output-channel count it takes                96
     X3D_OPT_COUNT
 };
 int x3d_opt(int id);

@@ -57,7 +57,7 @@ static DwGeom make_geom(int N, int C, int T, int H, int W, int stride, bool back
     g.ipc = th * g.groups;
     int cpb = 256 / g.ipc;
     if (cpb < 1) cpb = 1;
-    if (cpb > 16) cpb = 16;
+    if (cpb > x3d_opt(X3D_OPT_DW_CPB_MAX)) cpb = x3d_opt(X3D_OPT_DW_CPB_MAX);
     if (cpb > C) cpb = C;
     g.cpb = cpb;
     g.tiles = cdiv(GH, th);

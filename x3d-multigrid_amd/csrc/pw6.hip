@@ -448,7 +448,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
 // shapes pw6 takes (the caller has checked: dense, packed weights present)
 bool x3d_pw6_ok(int K, int M, int P) {
     const bool off = x3d_opt(X3D_OPT_NO_PW6) != 0;
-    return !off && K >= 64 && K <= P6_RP * P6_MAXPASS && M >= 96 && (P % 4 == 0) && P >= 4;
+    return !off && K >= 64 && K <= P6_RP * P6_MAXPASS && M >= x3d_opt(X3D_OPT_PW6_MIN_M) && (P % 4 == 0) && P >= 4;
 }
 
 int x3d_pw6_tiles(int P) { return cdiv(P, P6_BN); }
