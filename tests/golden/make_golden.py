@@ -249,6 +249,9 @@ def main():
         # the two literal shapes of the config with num_splits = B / 8
         jobs["train_M_64x4x112_s8"] = lambda: train_case(ref, "M", 64, 4, 112, 8)
         jobs["train_M_16x16x224_s2"] = lambda: train_case(ref, "M", 16, 16, 224, 2)
+        # the largest-N shape of the reference's own shape table (long cycle 0, short-cycle step 0): B = 128 per GPU,
+        # T = 4, odd 111 x 111 crop, 8 BN splits of 16 samples
+        jobs["train_M_128x4x111_s8"] = lambda: train_case(ref, "M", 128, 4, 111, 8)
     if args.big:
         # BASELINE config 5's literal clip shape (T = 16, H = W = 312) on the "L" architecture, B = 2
         jobs["train_L_2x16x312_s1"] = lambda: train_case(ref, "L", 2, 16, 312, 1, seed=4, second_draw_threads=1)

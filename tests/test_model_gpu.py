@@ -36,7 +36,9 @@ def _build(version, S, dev, seed=0):
 TRAIN_CASES = ["train_M_2x4x32_s1", "train_M_8x4x64_s2", "train_M_16x2x47_s4", "train_M_2x4x111_s1",
                "train_M_2x4x158_s2", "train_M_2x8x112_s1", "train_M_8x16x224_s1",
                # BASELINE config 3 at full per-GPU batch: the two literal multigrid shapes, num_splits = B / 8
-               "train_M_64x4x112_s8", "train_M_16x16x224_s2"]
+               "train_M_64x4x112_s8", "train_M_16x16x224_s2",
+               # the largest-N shape of the reference's own shape table: long cycle 0, B = 128 per GPU, odd 111^2 crop
+               "train_M_128x4x111_s8"]
 
 
 # + X3D-XL widths; + the "L" architecture of BASELINE config 5 (XL depth, M widths), incl. its literal clip shape 16 x 312 x 312
