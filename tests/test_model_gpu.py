@@ -172,6 +172,40 @@ def test_train_step_is_bitwise_reproducible_with_poisoned_lds(golden_dir, case):
     assert not bad, "%d tensors differ with poisoned LDS, first %s" % (len(bad), bad[:8])
 
 
+@pytest.mark.parametrize("case", ["train_M_2x4x158_s2", "train_M_2x4x111_s1", "train_M_16x2x47_s4", "train_M_8x4x64_s2",
+                                  "train_M_2x8x112_s1", "train_XL_2x4x64_s1"])
+def test_train_step_writes_nothing_out_of_bounds(golden_dir, case):
+    """Guard-band allocation (x3dhip.ops.set_guard): every buffer of the step -- activations, gradients, statistics and
+    weight-gradient partials, coefficient arrays, the weight packs -- sits between two 4 KB canary bands; after forward +
+    backward (+ the eval forward) every canary must be intact.  An out-of-bounds write corrupts whichever live tensor the
+    caching allocator placed next to the victim, so its effect depends on what the process ran before (a candidate for
+    GPUTEST_r02's box-dependent failure that no output-parity test can see); odd planes (79, 47, 111 -> 56 -> ... -> 4),
+    P % 4 != 0 and the tail tiles are where a vector store could overrun."""
+    from x3dhip import ops
+    dev = _dev()
+    g = _golden(golden_dir, case)
+    B, T, H, S = [int(v) for v in g["shape"]]
+    x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1])).to(dev)
+    y = synthetic.synthetic_labels(B, seed=int(g["seed"][1])).to(dev)
+    prev = ops.set_guard(True)
+    try:
+        net = _build(case.split("_")[1], S, dev, int(g["seed"][0]))
+        net.train(True)
+        logits = net(x)
+        loss = torch.nn.CrossEntropyLoss()(logits, y)
+        loss.backward()
+        net.train(False)
+        net.aggregate_sub_bn_stats()
+        with torch.no_grad():
+            net(x)
+        torch.cuda.synchronize()
+        assert len(ops._guarded) > 500                   # the step's buffers really were guarded
+        bad = ops.check_guards()
+        assert not bad, "%d buffers written out of bounds, first: %s" % (len(bad), bad[:6])
+    finally:
+        ops.set_guard(prev)
+
+
 def test_loc_head_vs_reference_golden(golden_dir):
     """task='loc' (x3d.py:240-241,340-343): per-frame logits [B, C, T], pooling over (H, W) only; forward, backward
     (same label on every frame) and eval against the reference's golden."""

@@ -75,9 +75,7 @@ class WeightPacks:
                 sizes.append(n)
                 items.append(int(L.x3d_pw_pack_items(K, M, 1 if transposed else 0)))
                 metas.append((w, transposed, M, K, 1 if transposed else ci, ci if transposed else 1))
-        self.buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        if ops.poisoned():
-            self.buf.fill_(float("nan"))
+        self.buf = ops._f((sum(sizes),), convs[0].data)      # (through ops._f: poison / guard modes cover the packs too)
         jobs = np.zeros(len(metas), dtype=dt)
         wg_job, off, wg = [], 0, 0
         self.views, self.ptrs = {}, []

@@ -72,7 +72,50 @@ def poisoned():
     return _poison
 
 
+# Guard mode (debug / tests): every buffer is allocated with GUARD elements of a canary pattern in front of and behind it;
+# `check_guards()` lists the buffers whose canaries a kernel has overwritten.  An out-of-bounds WRITE lands in whatever
+# tensor the caching allocator happened to place next to the victim -- i.e. its effect depends on what ran earlier in the
+# process -- and no parity test of the kernel's own output can see it; the canaries make it deterministic.
+GUARD = 1024
+_CANARY = {4: 0x5EEDBEEF - (1 << 32) if 0x5EEDBEEF >= (1 << 31) else 0x5EEDBEEF, 2: 0x5EED, 1: 0x5E, 8: 0x5EEDBEEF5EEDBEEF}
+_INT_OF = {4: torch.int32, 2: torch.int16, 1: torch.uint8, 8: torch.int64}
+_guard = False
+_guarded = []
+
+
+def set_guard(on):
+    """Turn guard-band allocation on / off (drops the record of earlier guarded buffers); returns the previous setting."""
+    global _guard
+    prev, _guard = _guard, bool(on)
+    del _guarded[:]
+    return prev
+
+
+def check_guards():
+    """[(shape, dtype, 'front' | 'back', first overwritten guard element)] of every guarded buffer a kernel wrote outside of."""
+    bad = []
+    for raw, n, shape, dtype in _guarded:
+        iv = raw.view(_INT_OF[raw.element_size()])
+        c = _CANARY[raw.element_size()]
+        for name, seg in (("front", iv[:GUARD]), ("back", iv[GUARD + n:])):
+            hit = (seg != c).nonzero()
+            if hit.numel():
+                bad.append((tuple(shape), str(dtype), name, int(hit[0])))
+    return bad
+
+
 def _f(shape, like, dtype=torch.float32):
+    if _guard:
+        n = 1
+        for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):
+            n *= int(d)
+        raw = torch.empty(n + 2 * GUARD, dtype=dtype, device=like.device)
+        raw.view(_INT_OF[raw.element_size()]).fill_(_CANARY[raw.element_size()])
+        t = raw[GUARD:GUARD + n].view(shape)
+        if _poison:
+            t.fill_(float("nan"))
+        _guarded.append((raw, n, shape, dtype))
+        return t
     t = torch.empty(shape, dtype=dtype, device=like.device)
     if _poison:
         t.fill_(float("nan"))
