@@ -33,6 +33,7 @@ enum X3DOpt {
     X3D_OPT_DW_TSPLIT_WGS,    // channelwise kernels: launches of at most this many workgroups split T in two      256 (0: never)
     X3D_OPT_DW_CPB_MAX,       // channelwise kernels: maximum channels per workgroup                               16
     X3D_OPT_PW6_MIN_M,        // whole-K forward kernel pw6: smallest output-channel count it takes                96
+    X3D_OPT_PW_TWO_TILES_K,   // whole-K kernels: padded K from which a wave takes two M tiles of one staged tile  320
     X3D_OPT_COUNT
 };
 int x3d_opt(int id);

@@ -96,8 +96,10 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
     }
     // this wave's A fragments: M tile (block mb, wave), planes behind the fp32 image of the pack
     const int mtiles = (M + 15) / 16;
-    const int mt = min(mb * A.mt_run + wave, mtiles - 1);                      // clamped: a duplicate is never stored
-    const bool mt_ok = wave < A.mt_run && mb * A.mt_run + wave < mtiles;
+    // (a block of more than 8 tiles -- K so large that one workgroup fills a CU's LDS, x3d_pw6_launch -- gives wave w the
+    // tiles w and w + 8: the staged activation tile is then shared by all M tiles of the layer instead of being staged twice)
+    int mt = min(mb * A.mt_run + wave, mtiles - 1);                            // clamped: a duplicate is never stored
+    bool mt_ok = wave < A.mt_run && mb * A.mt_run + wave < mtiles;
     const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
     const size_t plane = (size_t)mtiles * kg32 * 512;
     const __bf16* wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;                // + s * 512 per k step, + plane per plane
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
     P6T(4);
 
     // ---- K loop: B fragments by transposed LDS reads, A fragments through the register ring
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[2];
     const int tr_off = (8 * q + (r >> 2)) * P6_LD + 4 * (r & 3);
     auto tr_frag = [&](const __bf16* pl, int s, int h2) -> bf16x8 {
         typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -171,7 +173,18 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
             acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bh, acc[h2], 0, 0, 0);
         }
     };
-    if (mt_ok) {                                  // wave-uniform: waves beyond the block's tiles only helped staging
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) {                            // second tile of this wave (blocks of more than 8 tiles): w + 8
+        if (A.mt_run <= 8) break;
+        mt_ok = wave + 8 < A.mt_run && mb * A.mt_run + wave + 8 < mtiles;
+        if (!mt_ok) break;
+        mt = mb * A.mt_run + wave + 8;
+        wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fetch_a(i, ah[i], am[i], al[i]);
+      }
+      if (mt_ok) {                                // wave-uniform: waves beyond the block's tiles only helped staging
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int s0 = 0; s0 < kg32; s0 += 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -201,6 +214,7 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
                 }
             }
         }
+      }
     }
 #ifdef X3D_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -312,8 +326,9 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
 
     // ---- this wave's A fragments (first ring entries), then the epilogue operands: both in flight across the barrier
     const int mtiles = (M + 15) / 16;
-    const int mt = min(mb * A.mt_run + wave, mtiles - 1);                      // clamped: a duplicate is never stored
-    const bool mt_ok = wave < A.mt_run && mb * A.mt_run + wave < mtiles;
+    // (blocks of more than 8 tiles -- large K, x3d_pw7_launch -- give wave w the tiles w and w + 8 of ONE staged dY tile)
+    int mt = min(mb * A.mt_run + wave, mtiles - 1);                            // clamped: a duplicate is never stored
+    bool mt_ok = wave < A.mt_run && mb * A.mt_run + wave < mtiles;
     const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
     const size_t plane = (size_t)mtiles * kg32 * 512;
     const __bf16* wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;
@@ -348,6 +363,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
     }
     const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
     float xv[4][2], mk[4][2], adv[4][2], esc[4], esh[4];
+    auto fetch_epi = [&]() {                      // epilogue operands of tile mt: requested behind its first A fragments
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int m = mt * 16 + 4 * q + e;
@@ -374,9 +390,11 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
             }
         }
     }
+    };
+    fetch_epi();
     __syncthreads();
 
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[2];
     const int tr_off = (8 * q + (r >> 2)) * P6_LD + 4 * (r & 3);
     auto tr_frag = [&](const __bf16* pln, int s, int h2) -> bf16x8 {
         typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -400,7 +418,19 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
             acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bh, acc[h2], 0, 0, 0);
         }
     };
-    if (mt_ok) {
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) {                            // second tile of this wave (blocks of more than 8 tiles): w + 8
+        if (A.mt_run <= 8) break;
+        mt_ok = wave + 8 < A.mt_run && mb * A.mt_run + wave + 8 < mtiles;
+        if (!mt_ok) break;
+        mt = mb * A.mt_run + wave + 8;
+        wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fetch_a(i, ah[i], am[i], al[i]);
+        fetch_epi();
+      }
+      if (mt_ok) {
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int s0 = 0; s0 < kg32; s0 += 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -440,6 +470,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
                 }
             }
         }
+      }
     }
 }
 
@@ -459,11 +490,14 @@ int x3d_pw6_launch(const void* x, const float* cin, const float* wp, void* y, fl
     A.x = x; A.cin = cin; A.wp = wp; A.y = y; A.partial = partial; A.x_bf = x_bf; A.y_bf = y_bf;
     A.N = N; A.K = K; A.M = M; A.P = P; A.tiles = cdiv(P, P6_BN); A.in_act = in_act;
     const int mtiles = cdiv(M, 16);
-    A.mblocks = cdiv(mtiles, 8);
+    const int kp = cdiv(K, 32) * 32;
+    // tiles per M block: 8 (one per wave), or 16 (two per wave) once K is so large that a workgroup's three planes take the
+    // better part of a CU's LDS anyway (one resident workgroup): the layer's M tiles then share ONE staged activation tile
+    const int per = kp >= x3d_opt(X3D_OPT_PW_TWO_TILES_K) ? 16 : 8;
+    A.mblocks = cdiv(mtiles, per);
     A.mt_run = cdiv(mtiles, A.mblocks);
     const int VT = N * A.tiles;
     const dim3 grid(cdiv(VT, 8) * 8 * A.mblocks), block(P6_NT);
-    const int kp = cdiv(K, 32) * 32;
     const size_t lds = (size_t)3 * kp * P6_LD * sizeof(__bf16);
     const int npass = cdiv(kp, P6_RP);
     // more than 64 KB of dynamic LDS (K > 256) has to be allowed per kernel once
@@ -511,11 +545,12 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
     A.N = N; A.K = K; A.M = M; A.P = T * H * W; A.tiles = cdiv(A.P, P6_BN); A.T = T; A.H = H; A.W = W;
     A.Ho = (H - 1) / 2 + 1; A.Wo = (W - 1) / 2 + 1;
     const int mtiles = cdiv(M, 16);
-    A.mblocks = cdiv(mtiles, 8);
+    const int kp = cdiv(K, 32) * 32;
+    const int per = kp >= x3d_opt(X3D_OPT_PW_TWO_TILES_K) ? 16 : 8;      // tiles per M block (see x3d_pw6_launch)
+    A.mblocks = cdiv(mtiles, per);
     A.mt_run = cdiv(mtiles, A.mblocks);
     const int VT = N * A.tiles;
     const dim3 grid(cdiv(VT, 8) * 8 * A.mblocks), block(P6_NT);
-    const int kp = cdiv(K, 32) * 32;
     const int ns = x3d_opt(X3D_OPT_BWD_TERMS) == 2 ? 2 : 3;
     const size_t lds = (size_t)ns * kp * P6_LD * sizeof(__bf16);
     const int npass = cdiv(kp, P6_RP);
