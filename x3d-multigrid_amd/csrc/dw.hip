@@ -209,6 +209,11 @@ __device__ __forceinline__ float lane_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));   // wave_shl:1
 }
 
+// Workgroup barrier of the T march: orders the LDS ring only.  The compiler implemented the __syncthreads() at the end of a
+// step as "global_store ... s_waitcnt vmcnt(0) ... s_barrier" (ISA of round 2's kernels): every step drained its own output
+// store and the raw input it had just requested.  Global memory needs no ordering here: a workgroup never reads what it wrote.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float dw_act_lo(int act) { return act == X3D_ACT_RELU ? 0.f : -__builtin_inff(); }
 
 // Forward.  LDS holds two planes (double buffer); every thread keeps the values of the three
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
                 if (wo + 3 < g.Wo) py[3] = o[3];
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (t == 5) DTR(5);
     };
 
@@ -836,7 +841,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
                 for (int i = 0; i < 4; ++i) if (w0 + i < g.W) po[i] = o[i];
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (t == 5) DTR(5);
     };
 
@@ -860,21 +865,24 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     DTR(6);
 
     // reductions: per channel of the block, over its ipc items, in item order
-    float* rb = lds;    // reuse the ring: [29][256]
+    // rb[thread][29]: a thread's 29 values are consecutive words (stride 29 across lanes: no bank conflicts on the write), and
+    // the summing lanes (consecutive k of one channel) read consecutive words; the [29][256] layout of round 2 put all lanes
+    // of a wave on 2-3 banks
+    float* rb = lds;    // reuse the ring
 #pragma unroll
-    for (int k = 0; k < 27; ++k) rb[k * 256 + tid] = valid ? dwacc[k] : 0.f;
-    rb[27 * 256 + tid] = valid ? s1 : 0.f;
-    rb[28 * 256 + tid] = valid ? s2 : 0.f;
+    for (int k = 0; k < 27; ++k) rb[tid * 29 + k] = valid ? dwacc[k] : 0.f;
+    rb[tid * 29 + 27] = valid ? s1 : 0.f;
+    rb[tid * 29 + 28] = valid ? s2 : 0.f;
     __syncthreads();
     for (int o = tid; o < g.cpb * 29; o += 256) {
         const int chn = o / 29, k = o - chn * 29;
         if (c0 + chn < g.C) {
             // four interleaved partial sums (fixed order): the LDS reads of a round are independent
-            const float* rp = rb + k * 256 + chn * g.ipc;
+            const float* rp = rb + (size_t)chn * g.ipc * 29 + k;
             float s0 = 0.f, s1_ = 0.f, s2_ = 0.f, s3 = 0.f;
             int i = 0;
-            for (; i + 3 < g.ipc; i += 4) { s0 += rp[i]; s1_ += rp[i + 1]; s2_ += rp[i + 2]; s3 += rp[i + 3]; }
-            for (; i < g.ipc; ++i) s0 += rp[i];
+            for (; i + 3 < g.ipc; i += 4) { s0 += rp[i * 29]; s1_ += rp[(i + 1) * 29]; s2_ += rp[(i + 2) * 29]; s3 += rp[(i + 3) * 29]; }
+            for (; i < g.ipc; ++i) s0 += rp[i * 29];
             const float s = (s0 + s1_) + (s2_ + s3);
             const int slots = g.tiles * g.tsegs;
             const size_t row_id = ((size_t)n * g.C + c0 + chn) * slots + slot_id;
