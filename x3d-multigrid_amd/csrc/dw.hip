@@ -177,7 +177,22 @@ __device__ __forceinline__ void fetch4(const float* __restrict__ base, const Chu
 }
 
 // activation applied while storing; everything outside the tensor is exact zero
-template <int NCH, int VW>
+// SH (stride-1 kernels): the staged rows sit ONE column further right in LDS (data column w at DW_PADL + 1 + w), so that
+// a thread's six window values w0 - 1 .. w0 + 4 start at a 16-byte boundary and come out of LDS as one b128 + one b64 --
+// halo columns and zero padding included.  Round 2 fetched the two halo values from the neighbour lanes (DPP) with an LDS
+// read for the wave-edge lanes and four selects per row: ~12 vector instructions per row and plane in kernels that are
+// bound by vector issue.  The price is the staging write: 4 + 8 + 4 bytes instead of one b128 per chunk.
+template <bool SH>
+__device__ __forceinline__ void stage4(float* slot, int loff, const float4& v) {
+    if (SH) {
+        float* p = slot + loff + 1;
+        p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    } else {
+        *reinterpret_cast<float4*>(slot + loff) = v;
+    }
+}
+
+template <int NCH, int VW, bool SH>
 __device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], bool tvalid, float act_lo,
                                           const float4 (&reg)[NCH]) {
     constexpr bool VEC = VW == 4;
@@ -194,19 +209,8 @@ __device__ __forceinline__ void store_act(float* slot, const Chunk (&ch)[NCH], b
         v.y = nv > 1 ? fmaxf(fmaf(sc, reg[i].y, sh), act_lo) : 0.f;
         v.z = nv > 2 ? fmaxf(fmaf(sc, reg[i].z, sh), act_lo) : 0.f;
         v.w = nv > 3 ? fmaxf(fmaf(sc, reg[i].w, sh), act_lo) : 0.f;
-        if (ch[i].loff >= 0) *reinterpret_cast<float4*>(slot + ch[i].loff) = v;
+        if (ch[i].loff >= 0) stage4<SH>(slot, ch[i].loff, v);
     }
-}
-
-// Value of the previous / next lane of the wave (DPP wave shift; lane 0 / 63 get 0).  The stencil window's two halo
-// columns of a row are the neighbouring threads' float4 ends: fetching them from LDS as scalars (addresses 4 k - 1 and
-// 4 k + 4: stride 4 over 32 banks) was a 4-way bank conflict on two of every three LDS reads -- SQ_LDS_BANK_CONFLICT /
-// SQ_LDS_IDX_ACTIVE = 0.72 (forward) / 0.79 (backward) in profiles/r02/a_pmc_sq.txt.
-__device__ __forceinline__ float lane_prev(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));   // wave_shr:1
-}
-__device__ __forceinline__ float lane_next(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));   // wave_shl:1
 }
 
 // Workgroup barrier of the T march: orders the LDS ring only.  The compiler implemented the __syncthreads() at the end of a
@@ -347,8 +351,8 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     }
     const float act_lo = dw_act_lo(A.pre_act);
     // ring slot of plane t: (t - t0) & 1
-    store_act<NCH, VW>(ring, ch, true, act_lo, reg);
-    store_act<NCH, VW>(ring + g.slot, ch, t0 + 1 < g.T, act_lo, reg1);
+    store_act<NCH, VW, STRIDE == 1>(ring, ch, true, act_lo, reg);
+    store_act<NCH, VW, STRIDE == 1>(ring + g.slot, ch, t0 + 1 < g.T, act_lo, reg1);
     __syncthreads();
 
     // LDS offset of this thread's first window element
@@ -356,21 +360,16 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     // stride 1: the halo columns come from the neighbour lanes (same row: consecutive threads); only the first / last lane
     // of a wave in the middle of a row still reads its one missing element from LDS -- one read per row whose other lanes
     // fetch a conflict-free dummy word; the first / last group of a row takes the zero padding
-    const int lane_ = tid & 63;
-    const bool g_first = grp == 0, g_last = grp == g.groups - 1;
-    const bool edgeL = lane_ == 0 && !g_first, edgeR = lane_ == 63 && !g_last;
-    const int eoff = edgeL ? woff : (edgeR ? woff + 5 : -1);
     auto read_plane = [&](const float* slot, float (&v)[NV]) {
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const float* rp = slot + woff + kh * g.WP;
             if (STRIDE == 1) {
-                const float4 m = *reinterpret_cast<const float4*>(rp + 1);
-                const float e = slot[eoff >= 0 ? eoff + kh * g.WP : (lane_ & 31)];
-                const float lft = lane_prev(m.w), rgt = lane_next(m.x);
-                v[kh * 6] = g_first ? 0.f : (edgeL ? e : lft);
-                v[kh * 6 + 1] = m.x; v[kh * 6 + 2] = m.y; v[kh * 6 + 3] = m.z; v[kh * 6 + 4] = m.w;
-                v[kh * 6 + 5] = g_last ? 0.f : (edgeR ? e : rgt);
+                // shifted rows (stage4): window column w0 - 1 sits at the aligned word woff + 1
+                const float4 a = *reinterpret_cast<const float4*>(rp + 1);
+                const float2 b = *reinterpret_cast<const float2*>(rp + 5);
+                v[kh * 6] = a.x; v[kh * 6 + 1] = a.y; v[kh * 6 + 2] = a.z; v[kh * 6 + 3] = a.w;
+                v[kh * 6 + 4] = b.x; v[kh * 6 + 5] = b.y;
             } else {
                 v[kh * 9] = rp[0];
                 const float4 a = *reinterpret_cast<const float4*>(rp + 1);
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
         }
         if (t == 5) DTR(3);
         // the slot of plane t, last read one barrier ago -> free for plane t+2
-        store_act<NCH, VW>(ring + (size_t)((t - t0) & 1) * g.slot, ch, more, act_lo, reg);
+        store_act<NCH, VW, STRIDE == 1>(ring + (size_t)((t - t0) & 1) * g.slot, ch, more, act_lo, reg);
         if (t == 5) DTR(4);
         if (valid) {
             float* py = A.y + ybase + (size_t)t * g.Ho * g.Wo;
@@ -463,7 +462,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
     if (t0 > 0) {
         // a later T segment: plane t0 - 1 is part of the first output's window -- staged through the free slot 0 (plane
         // t0 + 1 sits in slot 1), read into the window, then slot 0 goes back to the march
-        store_act<NCH, VW>(ring, ch, true, act_lo, regm);
+        store_act<NCH, VW, STRIDE == 1>(ring, ch, true, act_lo, regm);
         __syncthreads();
         if (valid) read_plane(ring, w0);
         __syncthreads();
@@ -514,7 +513,7 @@ struct DwBwdArgs {
     const float* gamma; const float* save; float* dgamma; float* dbeta;
 };
 
-template <int NCH, int VW>
+template <int NCH, int VW, bool SH>
 __device__ __forceinline__ void store_dy(float* slot, const Chunk (&ch)[NCH], bool tvalid, const float (&k0)[NCH],
                                          const float (&k1)[NCH], const float (&k2)[NCH], const float4 (&rg)[NCH],
                                          const float4 (&ra)[NCH]) {
@@ -529,7 +528,7 @@ __device__ __forceinline__ void store_dy(float* slot, const Chunk (&ch)[NCH], bo
                 if (VEC || ch[i].nval > 2) v.z = fmaf(k0[i], rg[i].z, fmaf(k1[i], ra[i].z, k2[i]));
                 if (VEC || ch[i].nval > 3) v.w = fmaf(k0[i], rg[i].w, fmaf(k1[i], ra[i].w, k2[i]));
             }
-            *reinterpret_cast<float4*>(slot + ch[i].loff) = v;
+            stage4<SH>(slot, ch[i].loff, v);
         }
     }
 }
@@ -662,8 +661,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         float4 rg1[NCH], ra1[NCH];                       // the second plane requested before the first is staged: one round trip less
         fetch4<NCH, VW, MX>(gb, ch, (t0 + 1) * plane_o, t0 + 1 < g.T, rg1);
         fetch4<NCH, VW, MX>(ab, ch, (t0 + 1) * plane_o, t0 + 1 < g.T, ra1);
-        store_dy<NCH, VW>(ring, ch, true, k0, k1, k2, rg, ra);
-        store_dy<NCH, VW>(ring + g.slot, ch, t0 + 1 < g.T, k0, k1, k2, rg1, ra1);
+        store_dy<NCH, VW, STRIDE == 1>(ring, ch, true, k0, k1, k2, rg, ra);
+        store_dy<NCH, VW, STRIDE == 1>(ring + g.slot, ch, t0 + 1 < g.T, k0, k1, k2, rg1, ra1);
     }
     __syncthreads();
 
@@ -681,22 +680,15 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         roff0 = cc * g.IH * g.WP + (hoA - ho_lo) * g.WP + DW_PADL + 2 * grp;
         roff1 = cc * g.IH * g.WP + ((par ? hoB : hoA) - ho_lo) * g.WP + DW_PADL + 2 * grp;
     }
-    // stride 1: halo columns from the neighbour lanes (see lane_prev): the scalar LDS reads were 4-way bank conflicts
-    const int lane_ = tid & 63;
-    const bool g_first = grp == 0, g_last = grp == g.groups - 1;
-    const bool edgeL = lane_ == 0 && !g_first, edgeR = lane_ == 63 && !g_last;
-    const int eoff = edgeL ? roff0 : (edgeR ? roff0 + 5 : -1);
     auto read_plane = [&](const float* slot, float (&v)[NV]) {
         if (STRIDE == 1) {
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const float* rp = slot + roff0 - kh * g.WP;
-                const float4 m = *reinterpret_cast<const float4*>(rp + 1);
-                const float e = slot[eoff >= 0 ? eoff - kh * g.WP : (lane_ & 31)];
-                const float lft = lane_prev(m.w), rgt = lane_next(m.x);
-                v[kh * 6] = g_first ? 0.f : (edgeL ? e : lft);
-                v[kh * 6 + 1] = m.x; v[kh * 6 + 2] = m.y; v[kh * 6 + 3] = m.z; v[kh * 6 + 4] = m.w;
-                v[kh * 6 + 5] = g_last ? 0.f : (edgeR ? e : rgt);
+                const float* rp = slot + roff0 - kh * g.WP;          // shifted rows (stage4): column w0 - 1 at the aligned word
+                const float4 a = *reinterpret_cast<const float4*>(rp + 1);
+                const float2 b = *reinterpret_cast<const float2*>(rp + 5);
+                v[kh * 6] = a.x; v[kh * 6 + 1] = a.y; v[kh * 6 + 2] = a.z; v[kh * 6 + 3] = a.w;
+                v[kh * 6 + 4] = b.x; v[kh * 6 + 5] = b.y;
             }
         } else {
             const float* ra_ = slot + roff0;
@@ -816,7 +808,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
         }
         if (t == 5) DTR(3);
         // all loads of this step (dY plane t+2, x of step t+1) are consumed before the output store is issued
-        store_dy<NCH, VW>(ring + (size_t)((t - t0) & 1) * g.slot, ch, more, k0, k1, k2, rg, ra);
+        store_dy<NCH, VW, STRIDE == 1>(ring + (size_t)((t - t0) & 1) * g.slot, ch, more, k0, k1, k2, rg, ra);
         if (t == 5) DTR(4);
         if (valid) {
             float* po = A.out + xbase + (size_t)t * g.H * g.W;
@@ -851,7 +843,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     if (valid) read_plane(ring, wv1);                    // dY plane t0
     __syncthreads();       // the first step overwrites slot 0: every wave must have read plane t0 first
     if (t0 > 0) {          // a later T segment: dY plane t0 - 1 through the free slot 0 into the window (see dw_fwd_kernel)
-        store_dy<NCH, VW>(ring, ch, true, k0, k1, k2, rgm, ram);
+        store_dy<NCH, VW, STRIDE == 1>(ring, ch, true, k0, k1, k2, rgm, ram);
         __syncthreads();
         if (valid) read_plane(ring, wv0);
         __syncthreads();
