@@ -69,7 +69,7 @@ int x3d_debug_poison_lds(void* sink, void* stream);
  *   fb_grid, pw_pgrid, pw_nt4_min, pw_no_persist, dw_th, dw_balance, dw_no_v2, no_pw6, no_pw7, no_pwfs, dgrad_f32,
  *   wgrad_f32, bwd_terms (3 = fp32-level three-term bf16 split of the backward GEMM operands, 2 = two-term, ~2^-16),
  *   no_wgrad4, wg_cpw, wg_cap, stem_wg_cap, dw_tsplit_wgs (channelwise launches of at most this many workgroups cut the T
- *   march into two segments; 0 = never), dw_cpb_max (channels per channelwise workgroup, <= 16),
+ *   march into two segments; 0 = never; backward kernel), dw_tsplit_wgs_fwd (the same for the forward kernel), dw_cpb_max (channels per channelwise workgroup, <= 16),
  *   pw6_min_m (smallest output-channel count the whole-K forward kernel takes), pw_two_tiles_k (padded K from which a wave
  *   of the whole-K kernels takes two M tiles of one staged tile).
  * Unknown name or out-of-range value: X3D_EINVAL. */

@@ -46,7 +46,8 @@ def test_option_table_set_get_reset():
         import __graft_entry__ as ge
         ge.build()
     names = _lib.option_names()
-    assert {"fb_grid", "bwd_terms", "dgrad_f32", "wgrad_f32", "dw_th", "no_pw6", "no_pw7", "no_pwfs", "dw_tsplit_wgs"} <= set(names)
+    assert {"fb_grid", "bwd_terms", "dgrad_f32", "wgrad_f32", "dw_th", "no_pw6", "no_pw7", "no_pwfs", "dw_tsplit_wgs", "dw_tsplit_wgs_fwd",
+            "pw_two_tiles_k"} <= set(names)
     assert _lib.get_option("bwd_terms") == 3 and _lib.get_option("fb_grid") == 512
     h = _lib.lib()
     assert h.x3d_pw_bwd_fused_groups(2, 24964) == 512

@@ -465,9 +465,9 @@ def test_dw333_fwd_bwd(case):
 @pytest.mark.parametrize("case", [(8, 432, 16, 7, 7, 1), (2, 10, 16, 14, 14, 1), (2, 3, 8, 28, 28, 2), (1, 7, 9, 7, 7, 1),
                                   (2, 40, 11, 5, 5, 2), (1, 2, 8, 40, 56, 1)])
 def test_dw333_t_segments_equal_the_single_march(case):
-    """Launches with fewer workgroups than CUs cut the T march into two segments (option dw_tsplit_wgs; the 7 x 7 planes of
-    stage 4 at the base shape).  Every output voxel is computed by the same arithmetic either way: y and dx BITWISE equal to
-    the unsplit launch (dw_tsplit_wgs = 0); statistics and weight gradients are sums over more partials: 1e-6."""
+    """Launches with fewer workgroups than CUs cut the T march into two segments (options dw_tsplit_wgs / dw_tsplit_wgs_fwd: the 7 x 7
+    planes of stage 4 at the base shape in both directions, the 14 x 14 planes of stage 3 forward).  Every output voxel is computed by the same arithmetic either way: y and dx BITWISE equal to
+    the unsplit launch (thresholds 0); statistics and weight gradients are sums over more partials: 1e-6."""
     from x3dhip import _lib, ops
     dev = _dev()
     N, C, T, H, W, s = case
@@ -479,7 +479,7 @@ def test_dw333_t_segments_equal_the_single_march(case):
     cb = to(torch.stack([1 + 0.1 * _g(N, C, seed=7), 0.1 * _g(N, C, seed=8), 0.05 * _g(N, C, seed=9)], -1))
 
     def run(wgs):
-        with _lib.options(dw_tsplit_wgs=wgs):
+        with _lib.options(dw_tsplit_wgs=wgs, dw_tsplit_wgs_fwd=wgs):
             y, p = ops.dw333_fwd(x, w, stride=s, pre=pre, pre_act=1)
             dx, dw, bp = ops.dw333_bwd(g, a, cb, w, x, stride=s, pre=pre, pre_act=1)
             return y, p, dx, dw, bp

@@ -55,6 +55,7 @@ const OptDef kOpts[X3D_OPT_COUNT] = {
     /* X3D_OPT_DW_CPB_MAX     */ {"dw_cpb_max", "X3D_DW_CPB_MAX", 16, 0},
     /* X3D_OPT_PW6_MIN_M      */ {"pw6_min_m", "X3D_PW6_MIN_M", 96, 0},
     /* X3D_OPT_PW_TWO_TILES_K */ {"pw_two_tiles_k", "X3D_PW_TWO_TILES_K", 320, 0},
+    /* X3D_OPT_DW_TSPLIT_WGS_FWD */ {"dw_tsplit_wgs_fwd", "X3D_DW_TSPLIT_WGS_FWD", 512, 0},
 };
 std::atomic<int> g_opt[X3D_OPT_COUNT];
 std::once_flag g_opt_once;
@@ -75,7 +76,7 @@ int opt_find(const char* name) {
 bool opt_valid(int id, int v) {
     switch (id) {
         case X3D_OPT_FB_GRID: case X3D_OPT_PW_PGRID: case X3D_OPT_WG_CAP: case X3D_OPT_STEM_WG_CAP: return v >= 1 && v <= 65535;
-        case X3D_OPT_PW_NT4_MIN: case X3D_OPT_DW_TSPLIT_WGS: return v >= 0;
+        case X3D_OPT_PW_NT4_MIN: case X3D_OPT_DW_TSPLIT_WGS: case X3D_OPT_DW_TSPLIT_WGS_FWD: return v >= 0;
         case X3D_OPT_DW_TH: case X3D_OPT_DW_CPB_MAX: return v >= 1 && v <= 16;
         case X3D_OPT_WG_CPW: return v >= 1 && v <= 4096;
         case X3D_OPT_PW6_MIN_M: case X3D_OPT_PW_TWO_TILES_K: return v >= 16 && v <= 4096;

@@ -34,6 +34,7 @@ enum X3DOpt {
     X3D_OPT_DW_CPB_MAX,       // channelwise kernels: maximum channels per workgroup                               16
     X3D_OPT_PW6_MIN_M,        // whole-K forward kernel pw6: smallest output-channel count it takes                96
     X3D_OPT_PW_TWO_TILES_K,   // whole-K kernels: padded K from which a wave takes two M tiles of one staged tile  320
+    X3D_OPT_DW_TSPLIT_WGS_FWD,  // the same threshold for the forward channelwise kernel (14 x 14 planes: 16.9 -> 14.7 us)  512
     X3D_OPT_COUNT
 };
 int x3d_opt(int id);
@@ -103,6 +104,27 @@ __device__ __forceinline__ float act_bwd(float s, int act) {
 // config 5: bf16 storage / fp32 accumulate).  `bf` is a launch-uniform flag; `i` is the ELEMENT index.  Arithmetic is
 // always fp32: bf16 -> fp32 is a 16-bit shift, fp32 -> bf16 rounds to nearest even (v_cvt_pk_bf16_f32).
 // ---------------------------------------------------------------------------------------
+// Three-term bf16 split of a PAIR of fp32 values (the operands of the pointwise MFMA kernels):
+// x = hi + mid + lo with hi = RN(x), mid = RN(x - hi), lo = RN(x - hi - mid); H / M / L hold (a, b) as packed bf16 (a in the low
+// half).  Written so that the compiler emits ONE v_cvt_pk_bf16_f32 per term and pair, widens the halves back with a shift and
+// a mask of the packed word, and subtracts with one v_pk_add_f32: 9 vector instructions per pair.  The plain
+// (__bf16)x / (float)h cast form compiled to 12 (every low half converted a second time on its own: ISA of round 3's
+// kernels) in kernels whose staging phase is bound by vector issue.  The values are those of the cast form, bit for bit.
+typedef float x3d_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned x3d_pack_bf16(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    const bf2 p = {(__bf16)a, (__bf16)b};
+    unsigned u = __builtin_bit_cast(unsigned, p);
+    asm("" : "+v"(u));            // opaque to the optimiser, which otherwise re-derives each half from a scalar conversion
+    return u;
+}
+__device__ __forceinline__ void x3d_split3_pair(float a, float b, unsigned& H, unsigned& M, unsigned& L) {
+    H = x3d_pack_bf16(a, b);
+    const x3d_f2 r1 = x3d_f2{a, b} - x3d_f2{__uint_as_float(H << 16), __uint_as_float(H & 0xffff0000u)};
+    M = x3d_pack_bf16(r1.x, r1.y);
+    const x3d_f2 r2 = r1 - x3d_f2{__uint_as_float(M << 16), __uint_as_float(M & 0xffff0000u)};
+    L = x3d_pack_bf16(r2.x, r2.y);
+}
 typedef __attribute__((ext_vector_type(4))) __bf16 x3d_bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 x3d_bf16x2;
 

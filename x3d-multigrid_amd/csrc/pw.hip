@@ -2027,15 +2027,12 @@ constexpr int W3_LD = 72;          // bf16 elements per LDS row
 // v = hi + mid + lo: three bf16 terms = all 24 significant bits of an fp32 value (mid = bf16(v - hi), lo = bf16(v - hi - mid));
 // the two-term kernels (NS = 2, option bwd_terms = 2) keep hi and mid
 __device__ __forceinline__ void split_bf16x4(const float (&v)[4], bf16x4& hi, bf16x4& mid, bf16x4& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 h = (__bf16)v[e];
-        const float r1 = v[e] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        hi[e] = h;
-        mid[e] = m;
-        lo[e] = (__bf16)(r1 - (float)m);
-    }
+    uint2 H, M, L;                                  // pairs (v0, v1), (v2, v3): x3d_split3_pair, common.h
+    x3d_split3_pair(v[0], v[1], H.x, M.x, L.x);
+    x3d_split3_pair(v[2], v[3], H.y, M.y, L.y);
+    hi = __builtin_bit_cast(bf16x4, H);
+    mid = __builtin_bit_cast(bf16x4, M);
+    lo = __builtin_bit_cast(bf16x4, L);
 }
 
 // CO x CI = output tile of a workgroup (dY channels x input channels): 128 x 64 for the wide layers, 64-row and

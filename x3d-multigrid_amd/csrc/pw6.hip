@@ -129,16 +129,15 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(cf[i].x, v[e], cf[i].y), A.in_act);
             }
-            bf16x2 he, ho, me, mo, le, lo;
+            float xs[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x0 = ok ? v[e] : 0.f;
-                const __bf16 h = (__bf16)x0;
-                const float r1 = x0 - (float)h;
-                const __bf16 m = (__bf16)r1;
-                const __bf16 l = (__bf16)(r1 - (float)m);
-                if (e & 1) { ho[e >> 1] = h; mo[e >> 1] = m; lo[e >> 1] = l; } else { he[e >> 1] = h; me[e >> 1] = m; le[e >> 1] = l; }
-            }
+            for (int e = 0; e < 4; ++e) xs[e] = ok ? v[e] : 0.f;
+            unsigned hE, mE, lE, hO, mO, lO;               // pairs (0, 2) and (1, 3): x3d_split3_pair, common.h
+            x3d_split3_pair(xs[0], xs[2], hE, mE, lE);
+            x3d_split3_pair(xs[1], xs[3], hO, mO, lO);
+            const bf16x2 he = __builtin_bit_cast(bf16x2, hE), ho = __builtin_bit_cast(bf16x2, hO);
+            const bf16x2 me = __builtin_bit_cast(bf16x2, mE), mo = __builtin_bit_cast(bf16x2, mO);
+            const bf16x2 le = __builtin_bit_cast(bf16x2, lE), lo = __builtin_bit_cast(bf16x2, lO);
             *reinterpret_cast<bf16x2*>(&Xh[row * P6_LD + colE]) = he;
             *reinterpret_cast<bf16x2*>(&Xh[row * P6_LD + colO]) = ho;
             *reinterpret_cast<bf16x2*>(&Xm[row * P6_LD + colE]) = me;
@@ -302,16 +301,15 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
                 const bool ok = pvv && row < K;
                 const float4 gw = widen4(rg[i], ga_bf), aw = widen4(ra[i], ga_bf);
                 const float gv[4] = {gw.x, gw.y, gw.z, gw.w}, av[4] = {aw.x, aw.y, aw.z, aw.w};
-                bf16x2 he, ho, me, mo, le, lo;
+                float xs[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x0 = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
-                    const __bf16 h = (__bf16)x0;
-                    const float r1 = x0 - (float)h;
-                    const __bf16 m = (__bf16)r1;
-                    const __bf16 l = (__bf16)(r1 - (float)m);
-                    if (e & 1) { ho[e >> 1] = h; mo[e >> 1] = m; lo[e >> 1] = l; } else { he[e >> 1] = h; me[e >> 1] = m; le[e >> 1] = l; }
-                }
+                for (int e = 0; e < 4; ++e) xs[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
+                unsigned hE, mE, lE, hO, mO, lO;               // pairs (0, 2) and (1, 3): x3d_split3_pair, common.h
+                x3d_split3_pair(xs[0], xs[2], hE, mE, lE);
+                x3d_split3_pair(xs[1], xs[3], hO, mO, lO);
+                const bf16x2 he = __builtin_bit_cast(bf16x2, hE), ho = __builtin_bit_cast(bf16x2, hO);
+                const bf16x2 me = __builtin_bit_cast(bf16x2, mE), mo = __builtin_bit_cast(bf16x2, mO);
+                const bf16x2 le = __builtin_bit_cast(bf16x2, lE), lo = __builtin_bit_cast(bf16x2, lO);
                 *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colE]) = he;
                 *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colO]) = ho;
                 *reinterpret_cast<bf16x2*>(&Dm[row * P6_LD + colE]) = me;

@@ -136,15 +136,12 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
     const int colE = (c4 & 32) + ((c4 & 31) >> 1), colO = colE + 16;
 
     auto put = [&](__bf16* plane_h, __bf16* plane_m, __bf16* plane_l, int row, const float (&v)[4]) {
-        bf16x2 he, ho, me, mo, le, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const __bf16 h = (__bf16)v[e];
-            const float r1 = v[e] - (float)h;
-            const __bf16 m = (__bf16)r1;
-            const __bf16 l = (__bf16)(r1 - (float)m);
-            if (e & 1) { ho[e >> 1] = h; mo[e >> 1] = m; lo[e >> 1] = l; } else { he[e >> 1] = h; me[e >> 1] = m; le[e >> 1] = l; }
-        }
+        unsigned hE, mE, lE, hO, mO, lO;               // pairs (0, 2) and (1, 3): x3d_split3_pair, common.h
+        x3d_split3_pair(v[0], v[2], hE, mE, lE);
+        x3d_split3_pair(v[1], v[3], hO, mO, lO);
+        const bf16x2 he = __builtin_bit_cast(bf16x2, hE), ho = __builtin_bit_cast(bf16x2, hO);
+        const bf16x2 me = __builtin_bit_cast(bf16x2, mE), mo = __builtin_bit_cast(bf16x2, mO);
+        const bf16x2 le = __builtin_bit_cast(bf16x2, lE), lo = __builtin_bit_cast(bf16x2, lO);
         *reinterpret_cast<bf16x2*>(&plane_h[row * F_LD + colE]) = he;
         *reinterpret_cast<bf16x2*>(&plane_h[row * F_LD + colO]) = ho;
         *reinterpret_cast<bf16x2*>(&plane_m[row * F_LD + colE]) = me;
@@ -580,16 +577,15 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(cf[i].x, v[e], cf[i].y), A.in_act);
                 }
-                bf16x2 he, ho, me, mo, le, lo;
+                float xs[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x0 = ok ? v[e] : 0.f;
-                    const __bf16 h = (__bf16)x0;
-                    const float r1 = x0 - (float)h;
-                    const __bf16 m = (__bf16)r1;
-                    const __bf16 l = (__bf16)(r1 - (float)m);
-                    if (e & 1) { ho[e >> 1] = h; mo[e >> 1] = m; lo[e >> 1] = l; } else { he[e >> 1] = h; me[e >> 1] = m; le[e >> 1] = l; }
-                }
+                for (int e = 0; e < 4; ++e) xs[e] = ok ? v[e] : 0.f;
+                unsigned hE, mE, lE, hO, mO, lO;               // pairs (0, 2) and (1, 3): x3d_split3_pair, common.h
+                x3d_split3_pair(xs[0], xs[2], hE, mE, lE);
+                x3d_split3_pair(xs[1], xs[3], hO, mO, lO);
+                const bf16x2 he = __builtin_bit_cast(bf16x2, hE), ho = __builtin_bit_cast(bf16x2, hO);
+                const bf16x2 me = __builtin_bit_cast(bf16x2, mE), mo = __builtin_bit_cast(bf16x2, mO);
+                const bf16x2 le = __builtin_bit_cast(bf16x2, lE), lo = __builtin_bit_cast(bf16x2, lO);
                 *reinterpret_cast<bf16x2*>(&Xh[row * F_LD + colE]) = he;
                 *reinterpret_cast<bf16x2*>(&Xh[row * F_LD + colO]) = ho;
                 *reinterpret_cast<bf16x2*>(&Xm[row * F_LD + colE]) = me;
