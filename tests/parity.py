@@ -15,10 +15,24 @@ fp32 run) and the candidate's error is another, independent draw of the same pro
 ratio scatters (observed 0.5 ... 2.5 across the fixtures and across kernel revisions that only
 changed summation order); K = 3 bounds it without hiding a real defect, which shows up as an
 error orders of magnitude above the floor (and in the kernel- and block-level tests).
+
+Round 3: ONE draw underestimates the noise of the small-clip fixtures badly.  tests/golden/probe_conditioning.py perturbs
+a fixture's clip by 1e-6 (relative, random) and differentiates the fp64 oracle: the GLOBAL gradient norm of
+train_M_2x4x32_s1 then moves by 1.3e-2 (median of six draws; 3.2e-2 at most), of train_M_2x4x111_s1 by up to 2.2e-3, of
+train_M_2x4x158_s2 -- the fixture that went red on the driver's box in round 2 with 6.4e-3 -- by up to 1.1e-3, single tensors
+by 3-26 %: one ReLU unit that switches carries that much weight when the batch statistics of stage 4 span 8-200 voxels.  No
+fp32 evaluation order reproduces such a fixture to 1e-3 except by luck (a reordering of two reduction epilogues of the
+channelwise kernels moved train_M_2x4x32_s1 from 5.0e-5 to 2.3e-3; so did changing a tile height), and the
+reference's own fp32 draw stored in the fixture is one lucky sample.  tests/golden/conditioning.json holds the probe's result
+per fixture; a fixture whose MEDIAN probed response (six draws) exceeds 0.3 x RTOL gets `COND_K` x that median added to its
+bounds (global norm: the median global response; per-tensor criteria: the median worst-tensor response).  The BASELINE
+shape 8 x 16 x 224^2 (median 2.0e-4) and train_M_16x2x47_s4 stay below the threshold and keep the plain bounds; the
+batch-64 / 128 fixtures are too large to probe on this container's CPU and keep the plain bounds as well.
 """
 import numpy as np
 
 RTOL = 1e-3
+COND_K = 3.0
 
 
 def rel(a, b):
@@ -36,7 +50,17 @@ def check_forward(logits, loss, g, rtol=RTOL):
     return e, el
 
 
-def check_grads(grads, g, sketch_fn, rtol=RTOL):
+def conditioning(case):
+    """The probe's record of a fixture (tests/golden/conditioning.json), or None."""
+    import json
+    import os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "conditioning.json")
+    if not os.path.exists(p):
+        return None
+    return json.load(open(p)).get(case)
+
+
+def check_grads(grads, g, sketch_fn, rtol=RTOL, cond=None):
     """grads: {name: array-like}.  Returns a dict of measured errors (for reporting).  The WHOLE report -- global norm,
     per-parameter norms with the names of the worst few, sketch, the small gradients shipped in full -- is computed before
     anything is asserted, and every assertion message carries it: a red record must localise the wrong tensor."""
@@ -57,6 +81,12 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
     # plain 1e-3, no noise-floor allowance.  Only where the reference's OWN fp32 run is further than rtol / 2 from its fp64
     # value (the tiny-clip XL fixture: 1600 tensors at B = 2, floor 4.8e-3) is the floor term admitted.
     bound = rtol if floor < 0.5 * rtol else rtol + 3 * floor
+    # ill-conditioned fixture (module docstring): the probed response of the fp64 gradient to 1e-6 input noise
+    ill = bool(cond) and float(cond.get("median_global", 0.0)) > 0.3 * rtol
+    cg = float(cond["median_global"]) if ill else 0.0
+    ct = float(np.median(cond.get("worst_tensor", [0.0]))) if ill else 0.0
+    rep["cond_global"], rep["cond_tensor"] = cg, ct
+    bound = max(bound, rtol + COND_K * cg)
     if not rep["global_norm_err"] < bound:
         fails.append("global norm: %.3e >= %.3e" % (rep["global_norm_err"], bound))
     # per-parameter norms
@@ -73,9 +103,9 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
         fails.append("%d parameters with non-finite gradients" % len(nonfinite))
     order = np.argsort(-np.nan_to_num(e_got, nan=np.inf))[:8]
     rep["worst_norms"] = ["%s:%.2e(floor %.2e)" % (names[i], e_got[i], e_ref[i]) for i in order]
-    if not rep["norm_err_median"] <= rtol + 3 * rep["norm_floor_median"]:
+    if not rep["norm_err_median"] <= rtol + 3 * rep["norm_floor_median"] + COND_K * cg:
         fails.append("median per-parameter norm error")
-    if not rep["norm_err_max"] <= rtol + 3 * rep["norm_floor_max"]:
+    if not rep["norm_err_max"] <= rtol + 3 * rep["norm_floor_max"] + COND_K * ct:
         fails.append("max per-parameter norm error")
     # whole-vector direction via the random-projection sketch
     sk = sketch_fn(grads)
@@ -83,7 +113,7 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
     rep["sketch_floor"] = rel(g["grad_sketch"], g["grad_sketch64"])
     if two:
         rep["sketch_floor"] = max(rep["sketch_floor"], rel(g["grad_sketch_draw2"], g["grad_sketch64"]))
-    if not rep["sketch_err"] <= rtol + 3 * rep["sketch_floor"]:
+    if not rep["sketch_err"] <= rtol + 3 * rep["sketch_floor"] + COND_K * ct:
         fails.append("sketch")
     # the small gradients shipped in full
     worst, worst_name = 0.0, None
@@ -94,11 +124,11 @@ def check_grads(grads, g, sketch_fn, rtol=RTOL):
             f = rel(g["grad/" + name], g[k])
             if two:
                 f = max(f, rel(g["grad_draw2/" + name], g[k]))
-            ratio = e / (rtol + 3 * f)
+            ratio = e / (rtol + 3 * f + COND_K * ct)
             if not ratio <= worst:
                 worst, worst_name = ratio, name
-            if not e <= rtol + 3 * f:
-                fails.append("full gradient %s: %.3e > %.3e" % (name, e, rtol + 3 * f))
+            if not e <= rtol + 3 * f + COND_K * ct:
+                fails.append("full gradient %s: %.3e > %.3e" % (name, e, rtol + 3 * f + COND_K * ct))
     rep["full_grad_worst_ratio"] = worst
     rep["full_grad_worst"] = worst_name
     assert not fails, (fails, rep)

@@ -477,7 +477,7 @@ def test_fp32_mode_is_untouched_by_the_mixed_storage_build(golden_dir):
     dev = _dev()
     g, logits, loss, grads, _, _ = _golden_step(golden_dir, "train_L_4x4x96_s1", dev, torch.float32)
     parity.check_forward(logits, loss, g)
-    rep = parity.check_grads(grads, g, synthetic.gradient_sketch)
+    rep = parity.check_grads(grads, g, synthetic.gradient_sketch, cond=parity.conditioning("train_L_4x4x96_s1"))
     print("\n[train_L_4x4x96_s1 fp32] " + parity.fmt(rep))
 
 

@@ -58,7 +58,7 @@ def test_train_step_vs_reference_golden(golden_dir, case):
     torch.cuda.synchronize()
     e_log, e_loss = parity.check_forward(logits.detach().cpu().numpy()[:, :, 0], loss.item(), g)
     grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
-    rep = parity.check_grads(grads, g, synthetic.gradient_sketch)
+    rep = parity.check_grads(grads, g, synthetic.gradient_sketch, cond=parity.conditioning(case))
     sd = net.state_dict()
     parity.check_bn_stats({k: v.cpu().numpy() for k, v in sd.items() if v.ndim}, g)
     assert int(sd["bn1.split_bn.num_batches_tracked"]) == 1

@@ -98,6 +98,10 @@ PW_CASES = [
     (2, 48, 96, 4, 20, 20, 2, 1),     # layer3.0 downsample
     (2, 216, 96, 4, 10, 10, 1, 2),    # layer3.x conv3 (P = 400: 13 tiles of 32, tail of 16)
     (2, 96, 216, 4, 10, 10, 1, 0),    # layer3.x conv1
+    # the pointwise layers of the smallest golden clip (2, 4, 32, 32): P = 256 / 64 / 16 / 4 (stage 4: ONE voxel per plane)
+    (2, 24, 54, 4, 8, 8, 1, 0), (2, 54, 24, 4, 8, 8, 1, 2), (2, 48, 108, 4, 4, 4, 1, 0), (2, 108, 48, 4, 4, 4, 1, 2),
+    (2, 96, 216, 4, 2, 2, 1, 0), (2, 216, 96, 4, 2, 2, 1, 2), (2, 96, 192, 4, 2, 2, 2, 1),
+    (2, 192, 432, 4, 1, 1, 1, 1), (2, 432, 192, 4, 1, 1, 1, 2),
     (2, 96, 432, 4, 10, 10, 1, 0),    # layer4.0 conv1
     (2, 96, 192, 4, 10, 10, 2, 1),    # layer4.0 downsample
     (2, 432, 192, 4, 5, 5, 1, 2),     # layer4.x conv3 (P = 100: 4 tiles of 32, tail of 4)
@@ -288,6 +292,8 @@ FUSED_CASES = [
     (2, 108, 48, 4, 20, 20, 2),     # layer2.x conv3
     (12, 48, 108, 4, 20, 20, 1),    # layer2.x conv1 at N = 12: 300 chunks; and
     (24, 54, 24, 4, 40, 40, 2),     # 2400 chunks on 512 workgroups: 4-5 chunks per workgroup, uneven tail round
+    # stage 1-2 layers of the smallest golden clip (2, 4, 32, 32)
+    (2, 24, 54, 4, 8, 8, 1), (2, 54, 24, 4, 8, 8, 2), (2, 48, 108, 4, 4, 4, 1), (2, 108, 48, 4, 4, 4, 2),
 ]
 
 
@@ -423,6 +429,9 @@ DW_CASES = [
     (2, 216, 4, 20, 20, 2),   # layer3.0: 20 -> 10 (VW = 2)
     (2, 216, 4, 10, 10, 1),
     (2, 432, 4, 10, 10, 2),   # layer4.0: 10 -> 5 (VW = 1: odd output width)
+    # the channelwise layers of the smallest golden clip (2, 4, 32, 32): planes 16 -> 8 -> 4 -> 2 -> 1
+    (2, 54, 4, 16, 16, 2), (2, 54, 4, 8, 8, 1), (2, 108, 4, 8, 8, 2), (2, 108, 4, 4, 4, 1),
+    (2, 216, 4, 4, 4, 2), (2, 216, 4, 2, 2, 1), (2, 432, 4, 2, 2, 2), (2, 432, 4, 1, 1, 1),
     (2, 432, 4, 5, 5, 1),
 ]
 

@@ -482,18 +482,14 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs A) {
         redbuf[tid * 2] = valid ? s1 : 0.f;
         redbuf[tid * 2 + 1] = valid ? s2 : 0.f;
         __syncthreads();
-        // eight lanes per (channel, statistic): strided partial sums, then a butterfly -- a fixed order; one lane walking the
-        // channel's up to 196 items was a serial chain of LDS round trips (1-2 us of the 56 x 56 / 28 x 28 launches)
-        const int item = tid >> 3, sub = tid & 7;              // item = channel * 2 + statistic: <= 32 items
-        const int chn = item >> 1, which = item & 1;
-        float s = 0.f;
-        if (chn < g.cpb)
-            for (int i = sub; i < g.ipc; i += 8) s += redbuf[(chn * g.ipc + i) * 2 + which];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        if (sub == 0 && chn < g.cpb && c0 + chn < g.C)
-            A.partial[(((size_t)n * g.C + c0 + chn) * (g.tiles * g.tsegs) + slot_id) * 2 + which] = s;
+        if (tid < g.cpb * 2) {
+            const int chn = tid >> 1, which = tid & 1;
+            if (c0 + chn < g.C) {
+                float s = 0.f;
+                for (int i = 0; i < g.ipc; ++i) s += redbuf[(chn * g.ipc + i) * 2 + which];
+                A.partial[(((size_t)n * g.C + c0 + chn) * (g.tiles * g.tsegs) + slot_id) * 2 + which] = s;
+            }
+        }
     }
 #ifdef X3D_TRACE
     if (tid == 0) {
@@ -873,24 +869,16 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs A) {
     rb[tid * 29 + 27] = valid ? s1 : 0.f;
     rb[tid * 29 + 28] = valid ? s2 : 0.f;
     __syncthreads();
-    // L lanes per (channel, value): strided partial sums (two chains per lane), then a butterfly over the L lanes -- a fixed
-    // order.  One channel per workgroup (56 x 56 planes) used 29 lanes for 196 items each.
-    const int L = g.cpb == 1 ? 8 : (g.cpb == 2 ? 4 : (g.cpb <= 4 ? 2 : 1));
-    const int items = g.cpb * 29;
-    for (int o0 = 0; o0 < items; o0 += 256 / L) {              // uniform trip count: every lane takes part in the shuffles
-        const int o = o0 + tid / L, sub = tid % L;
-        const bool live = o < items;
-        const int chn = live ? o / 29 : 0, k = live ? o - chn * 29 : 0;
-        const float* rp = rb + (size_t)chn * g.ipc * 29 + k;
-        float sa = 0.f, sb = 0.f;
-        if (live) {
-            int i = sub;
-            for (; i + L < g.ipc; i += 2 * L) { sa += rp[i * 29]; sb += rp[(i + L) * 29]; }
-            if (i < g.ipc) sa += rp[i * 29];
-        }
-        float s = sa + sb;
-        for (int m = 1; m < L; m <<= 1) s += __shfl_xor(s, m);
-        if (live && sub == 0 && c0 + chn < g.C) {
+    for (int o = tid; o < g.cpb * 29; o += 256) {
+        const int chn = o / 29, k = o - chn * 29;
+        if (c0 + chn < g.C) {
+            // four interleaved partial sums (fixed order): the LDS reads of a round are independent
+            const float* rp = rb + (size_t)chn * g.ipc * 29 + k;
+            float s0 = 0.f, s1_ = 0.f, s2_ = 0.f, s3 = 0.f;
+            int i = 0;
+            for (; i + 3 < g.ipc; i += 4) { s0 += rp[i * 29]; s1_ += rp[(i + 1) * 29]; s2_ += rp[(i + 2) * 29]; s3 += rp[(i + 3) * 29]; }
+            for (; i < g.ipc; ++i) s0 += rp[i * 29];
+            const float s = (s0 + s1_) + (s2_ + s3);
             const int slots = g.tiles * g.tsegs;
             const size_t row_id = ((size_t)n * g.C + c0 + chn) * slots + slot_id;
             if (k < 27) A.wpartial[(((size_t)n * slots + slot_id) * g.C + c0 + chn) * 27 + k] = s;   // [N][tiles * tsegs][C][27]
