@@ -78,6 +78,43 @@ def test_train_step_vs_reference_golden(golden_dir, case):
     assert parity.rel(ev.cpu().numpy()[:, :, 0], g["eval_logits"]) < parity.RTOL
 
 
+def test_small_fixture_gradient_is_sensitive_to_summation_order(golden_dir):
+    """tests/parity.py, DESIGN.md 4.7: the gradient of a small-clip fixture is not reproducible to 1e-3 by fp32 arithmetic.
+    The smallest fixture twice: default tiling of the channelwise kernels, and `dw_th = 4` -- the 8 x 8 planes of stage 1 in
+    two row tiles instead of one, i.e. the same numbers summed in another order (every kernel-level test passes with either).
+    The two gradients differ by more than the plain bound although nothing is wrong with either; both must satisfy the
+    conditioning-aware criteria, and the forward passes (logits, loss) must agree far inside their 1e-3 bound."""
+    from x3dhip import _lib
+    case = "train_M_2x4x32_s1"
+    dev = _dev()
+    g = _golden(golden_dir, case)
+    B, T, H, S = [int(v) for v in g["shape"]]
+    x = synthetic.synthetic_clips(B, T, H, H, seed=int(g["seed"][1])).to(dev)
+    y = synthetic.synthetic_labels(B, seed=int(g["seed"][1])).to(dev)
+
+    def run(**opts):
+        with _lib.options(**opts):
+            net = _build("M", S, dev, int(g["seed"][0]))
+            net.train(True)
+            logits = net(x)
+            loss = torch.nn.CrossEntropyLoss()(logits, y)
+            loss.backward()
+            torch.cuda.synchronize()
+        grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
+        parity.check_forward(logits.detach().cpu().numpy()[:, :, 0], loss.item(), g)
+        rep = parity.check_grads(grads, g, synthetic.gradient_sketch, cond=parity.conditioning(case))
+        return logits.detach().cpu().numpy(), grads, rep
+
+    l0, g0, r0 = run()
+    l1, g1, r1 = run(dw_th=4)
+    assert parity.rel(l1, l0) < 2e-4           # measured 3.6e-5: the forward passes agree far inside the 1e-3 bound
+    tot = lambda gr: float(np.sqrt(sum(float((np.asarray(v, np.float64) ** 2).sum()) for v in gr.values())))
+    diff = abs(tot(g1) - tot(g0)) / tot(g0)
+    print("\n[%s] global norm vs fp64: default tiling %.2e, dw_th=4 %.2e; the two runs differ by %.2e (probed conditioning %.2e)"
+          % (case, r0["global_norm_err"], r1["global_norm_err"], diff, r0["cond_global"]))
+    assert r0["cond_global"] > 1e-3            # the probe's record says so in advance
+
+
 @pytest.mark.parametrize("case", ["train_M_2x4x158_s2", "train_M_8x4x64_s2"])
 def test_train_step_is_bitwise_reproducible_under_poisoned_allocations(golden_dir, case):
     """The same step three times in one process: as is, with every buffer the ops allocate NaN-filled first

@@ -138,3 +138,16 @@ def test_shape_table_matches_survey():
         got = [mo.step_shape(li, t, 80, 5) for t in range(len(shapes))]
         assert got == shapes
     assert mo.lr_milestones(206160) == [82464, 134004, 190698, 206160]
+
+
+def test_conditioning_table_covers_the_small_fixtures(golden_dir):
+    """tests/golden/conditioning.json (written by tests/golden/probe_conditioning.py from the fp64 oracle) has a record for
+    every training fixture small enough to differentiate in fp64 on a CPU, and the records say what tests/parity.py relies on:
+    the small clips respond to 1e-6 input noise at or above the 1e-3 level, the BASELINE shape stays below the threshold."""
+    tab = {c: parity.conditioning(c) for c in ("train_M_2x4x32_s1", "train_M_8x4x64_s2", "train_M_16x2x47_s4", "train_M_2x4x111_s1",
+                                               "train_M_2x4x158_s2", "train_M_2x8x112_s1", "train_M_8x16x224_s1",
+                                               "train_XL_2x4x64_s1", "train_L_4x4x96_s1")}
+    assert all(v is not None and v["eps"] == 1e-6 and len(v["global"]) >= 3 for v in tab.values()), tab
+    assert tab["train_M_2x4x32_s1"]["median_global"] > 3e-3
+    assert tab["train_M_2x4x158_s2"]["max_global"] > 5e-4
+    assert tab["train_M_8x16x224_s1"]["median_global"] < 3e-4
