@@ -11,7 +11,7 @@ Prints ONE JSON line (rank 0): clips/s over the whole job, plus
                   algorithmic bytes (in+out elements of each conv pass) over
                   its HIP-event-measured duration, vs the 8 TB/s HBM peak
   cpu_baseline -- the CPU oracle (stock-PyTorch restatement of the reference) timed on the
-                  host cores on a bounded sample (B=2 of the same shape), rank 0, N=1 only.
+                  host cores on the stated workload (B=8 steps, bounded to ~1 minute), rank 0, N=1 only.
 """
 import argparse
 import json
@@ -209,36 +209,41 @@ def _cpu_share():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(T, H, sample_B=2, budget_s=10.0, min_steps=3, max_steps=8):
-    """CPU oracle (stock-PyTorch restatement of the reference, oracle/x3d_oracle.py) on the host cores: fwd+bwd of X3D-M on a
-    B = 2 sample of the headline clip shape, at ALL cores of this process's CPU share (_cpu_share) and at 8 threads (SURVEY.md 8(d):
-    the 8-thread figure ties back to BASELINE.md's measurement of the reference itself in the 8-core build container)."""
+def cpu_baseline(T, H, B=8, sample_B=2):
+    """CPU oracle (stock-PyTorch restatement of the reference, oracle/x3d_oracle.py) on the host cores: fwd+bwd of X3D-M ON THE
+    STATED WORKLOAD (B = 8 clips of the headline shape; round 4 -- earlier rounds timed a B = 2 sample only), at ALL cores of
+    this process's CPU share (_cpu_share) and at 8 threads (the 8-thread figure ties back to BASELINE.md's
+    measurement of the reference itself in the 8-core build container).  Bounded: one warm-up + 3 steps at all cores, one
+    warm-up + 2 steps at 8 threads, plus the old B = 2 sample (3 steps) for continuity with BENCH_r01..r03 -- about a minute."""
     from oracle import x3d_oracle as xo
     from x3dhip import synthetic
     avail = _cpu_share()
     sd = synthetic.procedural_state_dict(xo.state_template("M", 400, 1), 0)
-    x = synthetic.synthetic_clips(sample_B, T, H, H)
-    y = synthetic.synthetic_labels(sample_B)
 
-    def timed(threads):
+    def timed(threads, batch, steps):
+        x = synthetic.synthetic_clips(batch, T, H, H)
+        y = synthetic.synthetic_labels(batch)
         torch.set_num_threads(threads)
-        print("[bench] cpu baseline: oracle fwd+bwd on %d threads ..." % threads, file=sys.stderr, flush=True)
+        print("[bench] cpu baseline: oracle fwd+bwd B=%d on %d threads ..." % (batch, threads), file=sys.stderr, flush=True)
         xo.train_step_grads(x, y, sd, "M", 1)         # warm-up
-        ts, t_begin = [], time.time()
-        while len(ts) < min_steps or (time.time() - t_begin < budget_s and len(ts) < max_steps):
+        ts = []
+        for _ in range(steps):
             t0 = time.time()
             xo.train_step_grads(x, y, sd, "M", 1)
             ts.append(time.time() - t0)
-            print("[bench] cpu baseline step %.2f s (%d threads)" % (ts[-1], threads), file=sys.stderr, flush=True)
-        return sorted(ts)[len(ts) // 2], len(ts)
+            print("[bench] cpu baseline step %.2f s (B=%d, %d threads)" % (ts[-1], batch, threads), file=sys.stderr, flush=True)
+        return sorted(ts)[len(ts) // 2]
 
-    t_all, n_all = timed(avail)
-    t_8, n_8 = timed(min(8, avail))
-    return {"value": round(sample_B / t_all, 3), "unit": "clips/s", "cores": avail, "kind": "port",
-            "value_8_threads": round(sample_B / t_8, 3), "cores_8": min(8, avail), "cpu_model": _cpu_model(),
+    t_all = timed(avail, B, 3)
+    t_8 = timed(min(8, avail), B, 2)
+    t_s = timed(avail, sample_B, 3)
+    return {"value": round(B / t_all, 3), "unit": "clips/s", "cores": avail, "kind": "port",
+            "value_8_threads": round(B / t_8, 3), "cores_8": min(8, avail), "cpu_model": _cpu_model(),
             "host_cpu_count": os.cpu_count(),
-            "sample": "oracle/x3d_oracle.py fwd+bwd, X3D-M B=%d T=%d H=W=%d fp32 (a B=2 sample of the B=8 workload), median of %d / %d "
-                      "steps at %d / %d torch CPU threads" % (sample_B, T, H, n_all, n_8, avail, min(8, avail))}
+            "value_B2_sample": round(sample_B / t_s, 3),
+            "sample": "oracle/x3d_oracle.py fwd+bwd, X3D-M B=%d T=%d H=W=%d fp32 = the stated workload (one step = one batch of %d "
+                      "clips), median of 3 / 2 steps at %d / %d torch CPU threads; value_B2_sample: the B=%d sample earlier "
+                      "rounds reported, 3 steps at %d threads" % (B, T, H, B, avail, min(8, avail), sample_B, avail)}
 
 
 def main():
@@ -255,6 +260,9 @@ def main():
                     help="bf16: mixed-storage mode -- the wide tensors inside the bottlenecks stored as bf16, fp32 arithmetic "
                          "(BASELINE configs[4]; the headline metric is quoted on f32)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-overlap", action="store_true", help="multi-rank: single graph + all-reduce after the whole backward")
+    ap.add_argument("--copy-input", action="store_true", help="copy the batch into the graph's input tensors every timed step "
+                    "(what rounds 1-2 measured; default: the clips are resident in the graph's inputs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the second timed run with the exact fp32-MFMA backward GEMMs")
@@ -293,7 +301,7 @@ def main():
     mixed = args.dtype == "bf16"
     net = x3d.generate_model(args.model, n_classes=400, dropout=0.5, base_bn_splits=max(1, B // 8),
                              act_dtype=torch.bfloat16 if mixed else torch.float32).to(dev).train(True)
-    tr = Trainer(net, lr=0.05, process_group=pg, world_size=world, use_graph=not args.no_graph)
+    tr = Trainer(net, lr=0.05, process_group=pg, world_size=world, use_graph=not args.no_graph, overlap=not args.no_overlap)
     x = synthetic.synthetic_clips(B, T, H, H, seed=1234 + rank).to(dev)
     y = synthetic.synthetic_labels(B, seed=1234 + rank).to(dev)
 
@@ -310,7 +318,8 @@ def main():
         for _ in range(args.warmup):
             tr.step(x, y)
         xs, ys = x, y
-        st = tr.static_inputs(x.shape) if tr.use_graph else None
+        st = tr.static_inputs(x.shape) if (tr.use_graph and not args.copy_input) else None
+        timed_run.input_copy = st is None and tr.use_graph      # graph mode without static inputs: one copy of x, y per step
         if st is not None:
             st[0].copy_(x)
             st[1].copy_(y)
@@ -367,6 +376,9 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "storage": "bf16 wide tensors / f32" if mixed else "f32",
                    "launch": "eager" if args.no_graph else "hipGraph(fwd+bwd) + SGD",
+                   # rounds 1-2 copied the batch into the graph's inputs every timed step (x: 77 MB at the
+                   # headline shape, ~0.05 ms); since round 3 the synthetic clips are resident there.  --copy-input restores it.
+                   "input_copy_per_step": bool(getattr(timed_run, "input_copy", False)),
                    # storage, forward GEMMs, stencils, BN: fp32.  Backward pointwise GEMMs: fp32 operands split into
                    # hi+lo bf16 (3 MFMA products, fp32 accumulate, ~2^-16 per product; parity-verified)
                    # unless X3D_DGRAD_F32 / X3D_WGRAD_F32 select the exact fp32-MFMA kernels
@@ -487,7 +499,7 @@ def main():
         out["kernel_breakdown_ms"] = {k: [round(v[0], 3), v[2], round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0]
                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "M":
-        out["cpu_baseline"] = cpu_baseline(T, H)
+        out["cpu_baseline"] = cpu_baseline(T, H, B)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

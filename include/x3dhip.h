@@ -102,8 +102,10 @@ int x3d_pw_bwd_tiles(int N, int Cin, int Cout, int P, int packed, int mx);
 /* Weight pre-packing for the tiled variant used on large-C layers (K >= 64 and M >= 96, see
  * x3d_pw_wants_packed): x3d_pw_pack writes w[Cout][Cin] into MFMA fragment order
  * (x3d_pw_pack_floats(K, M, transposed) floats, zero padded); transposed = 1 packs the backward-data
- * operand (M = Cin, K = Cout) and appends its split-bf16 image (hi = bf16(w), lo = bf16(w - hi) in
- * 16x16x32 MFMA fragment order) used by the split-precision data-gradient kernel.
+ * operand (M = Cin, K = Cout).  Behind the fp32 image every pack carries THREE bf16 planes in 16x16x32 MFMA
+ * fragment order (hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid): all 24 significant bits) -- in
+ * both orientations since ABI 6; the split-precision forward, data-gradient, fused and weight-gradient
+ * kernels read them (a two-term kernel reads hi and mid).
  * Weights change every optimizer step: pack once per step.
  * Passing NULL for wpacked selects the streaming kernel (same results, same `partial` shape). */
 int x3d_pw_wants_packed(int K, int M);
@@ -112,7 +114,9 @@ size_t x3d_pw_pack_items(int K, int M, int transposed);   /* work items (256 per
 int x3d_pw_pack(const float* w, float* wp, int Cout, int Cin, int transposed, void* stream);
 /* Batched packing: `jobs` is a device array of records
  *   { const float* w; float* wp; int M, K, ldm, ldk, mtiles, kgroups, wg0, with_bf16; }   (x3d_pw_pack_job_bytes() each;
- *   A[row][k] = w[row*ldm + k*ldk], mtiles = ceil(M/16), kgroups = ceil(K/16), wg0 = first workgroup of the job)
+ *   A[row][k] = w[row*ldm + k*ldk], mtiles = ceil(M/16), kgroups = ceil(K/16), wg0 = first workgroup of the job;
+ *   with_bf16: 0 = fp32 image only, any other value = the three bf16 planes as well -- since ABI 6 the kernels
+ *   need them: pass 3.  x3d_pw_pack_floats / _items always size a pack for three planes)
  * and wg_job[n_workgroups] maps every 256-element workgroup to its job. */
 size_t x3d_pw_pack_job_bytes(void);
 int x3d_pw_pack_batch(const void* jobs, const int* wg_job, int n_workgroups, void* stream);

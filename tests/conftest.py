@@ -40,6 +40,8 @@ def pytest_collection_modifyitems(config, items):
             return (0, 0, 0, idx)
         fname = os.path.basename(str(it.fspath))
         rank = _FILE_RANK.get(fname, 3)
+        if fname == "test_determinism_gpu.py":                  # the committed-hash comparison: right before the goldens it pins
+            return (3, 0, 1 << 60, idx)
         if fname == "test_model_gpu.py" and it.name.split("[")[0] in _GOLDEN_TESTS:
             return (3, 1, _clip_elems(it.nodeid), idx)         # whole-network goldens: after the block tests, small -> large
         return (rank, 0, 0, idx)

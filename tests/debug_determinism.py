@@ -54,14 +54,10 @@ from x3dhip.trainer import Trainer  # noqa: E402
 
 
 def run_trainer(split):
-    if split:
-        os.environ["X3D_FORCE_SPLIT"] = "1"
-    else:
-        os.environ.pop("X3D_FORCE_SPLIT", None)
     net = x3d.generate_model("M", n_classes=400, dropout=0.0, base_bn_splits=S)
     net.load_state_dict(sd)
     net.to(dev).train(True)
-    tr = Trainer(net, lr=0.05, use_graph=True)
+    tr = Trainer(net, lr=0.05, use_graph=True, force_split=split)
     poison_pool()
     out = []
     for _ in range(2):

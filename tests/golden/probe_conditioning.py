@@ -46,17 +46,22 @@ def probe(case, K=6, eps=3e-7):
     ref = abs(tot0 - float(g["grad_global_norm64"])) / float(g["grad_global_norm64"])
     print("%s: oracle fp64 global norm vs fixture %.2e" % (case, ref), flush=True)
     out, outt = [], []
+    per = {n: [] for n in g0}                      # per-tensor responses (round 4: tests/parity.py allows per NAME)
     for k in range(K):
         torch.manual_seed(1000 + k)
         gi = grads(x * (1 + eps * torch.randn_like(x)))
         tot = float(torch.sqrt(sum((v ** 2).sum() for v in gi.values())))
-        w = max((float((gi[n] - g0[n]).norm() / (g0[n].norm() + 1e-300)), n) for n in g0)
+        for n in g0:
+            per[n].append(float((gi[n] - g0[n]).norm() / (g0[n].norm() + 1e-300)))
+        w = max((per[n][-1], n) for n in g0)
         out.append(abs(tot - tot0) / tot0)
         outt.append(w[0])
         print("  perturbation %d (%.0e): global norm %.3e   worst tensor %s %.3e" % (k, eps, out[-1], w[1], w[0]), flush=True)
     print("CONDITIONING %s max_global %.3e median_global %.3e" % (case, max(out), float(np.median(out))), flush=True)
     return {"case": case, "eps": eps, "K": K, "global": out, "max_global": max(out), "median_global": float(np.median(out)),
-            "worst_tensor": outt, "max_tensor": max(outt)}
+            "worst_tensor": outt, "max_tensor": max(outt),
+            # median response of every tensor that moves by more than 1e-4 (the others: 0); order-free, keyed by name
+            "tensor_median": {n: float(np.median(v)) for n, v in per.items() if float(np.median(v)) > 1e-4}}
 
 
 if __name__ == "__main__":

@@ -477,7 +477,9 @@ def test_fp32_mode_is_untouched_by_the_mixed_storage_build(golden_dir):
     dev = _dev()
     g, logits, loss, grads, _, _ = _golden_step(golden_dir, "train_L_4x4x96_s1", dev, torch.float32)
     parity.check_forward(logits, loss, g)
-    rep = parity.check_grads(grads, g, synthetic.gradient_sketch, cond=parity.conditioning("train_L_4x4x96_s1"))
+    from tests import gradhash
+    rep = parity.check_grads(grads, g, synthetic.gradient_sketch, cond=parity.conditioning("train_L_4x4x96_s1"),
+                             case="train_L_4x4x96_s1", pinned="train_L_4x4x96_s1" in gradhash.pinned_cases())
     print("\n[train_L_4x4x96_s1 fp32] " + parity.fmt(rep))
 
 

@@ -58,7 +58,11 @@ def test_train_step_vs_reference_golden(golden_dir, case):
     torch.cuda.synchronize()
     e_log, e_loss = parity.check_forward(logits.detach().cpu().numpy()[:, :, 0], loss.item(), g)
     grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
-    rep = parity.check_grads(grads, g, synthetic.gradient_sketch, cond=parity.conditioning(case))
+    # pinned: the bitwise result of this case on these kernel sources is committed (tests/golden/grad_hashes.json, compared by
+    # tests/test_determinism_gpu.py, which runs first) -> plain bounds, no conditioning allowance
+    from tests import gradhash
+    rep = parity.check_grads(grads, g, synthetic.gradient_sketch, cond=parity.conditioning(case), case=case,
+                             pinned=case in gradhash.pinned_cases())
     sd = net.state_dict()
     parity.check_bn_stats({k: v.cpu().numpy() for k, v in sd.items() if v.ndim}, g)
     assert int(sd["bn1.split_bn.num_batches_tracked"]) == 1
@@ -102,7 +106,9 @@ def test_small_fixture_gradient_is_sensitive_to_summation_order(golden_dir):
             torch.cuda.synchronize()
         grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
         parity.check_forward(logits.detach().cpu().numpy()[:, :, 0], loss.item(), g)
-        rep = parity.check_grads(grads, g, synthetic.gradient_sketch, cond=parity.conditioning(case))
+        # (never pinned: the second run changes the summation order on purpose)
+        rep = parity.check_grads(grads, g, synthetic.gradient_sketch, cond=parity.conditioning(case), case=case)
+        rep["cond_global"] = float(parity.conditioning(case)["median_global"])
         return logits.detach().cpu().numpy(), grads, rep
 
     l0, g0, r0 = run()

@@ -138,14 +138,10 @@ def test_split_graph_backward_equals_single_graph(monkeypatch):
     y = synthetic.synthetic_labels(4, seed=5).to(dev)
     res = []
     for split in (False, True):
-        if split:
-            monkeypatch.setenv("X3D_FORCE_SPLIT", "1")
-        else:
-            monkeypatch.delenv("X3D_FORCE_SPLIT", raising=False)
         model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=2)
         model.load_state_dict(synthetic.procedural_state_dict(xo.state_template("M", 400, 2), 1))
         model.to(dev).train(True)
-        tr = Trainer(model, lr=0.05, use_graph=True)
+        tr = Trainer(model, lr=0.05, use_graph=True, force_split=split)
         assert tr._overlap() == split
         for _ in range(2):                       # capture + one replay
             loss, logits = tr.train_step(x, y)
@@ -437,15 +433,11 @@ def test_rccl_world_size_one_split_graph(monkeypatch):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         for split in (False, True):
-            if split:
-                monkeypatch.setenv("X3D_FORCE_SPLIT", "1")
-            else:
-                monkeypatch.delenv("X3D_FORCE_SPLIT", raising=False)
             model = resnet_x3d.generate_model(x3d_version="M", n_classes=400, dropout=0.0, base_bn_splits=2)
             model.load_state_dict(synthetic.procedural_state_dict(xo.state_template("M", 400, 2), 1))
             model.to(dev).train(True)
-            monkeypatch.setenv("X3D_FORCE_COLLECTIVES", "1" if split else "0")      # one-rank group: still all-reduce
-            tr = Trainer(model, lr=0.05, use_graph=True, process_group=dist.group.WORLD, world_size=1)
+            tr = Trainer(model, lr=0.05, use_graph=True, process_group=dist.group.WORLD, world_size=1,
+                         force_split=split, force_collectives=split)      # one-rank group: still all-reduce
             assert tr.reducer.active == split and tr._overlap() == split
             for _ in range(3):
                 loss, _ = tr.train_step(x, y)

@@ -60,13 +60,23 @@ const OptDef kOpts[X3D_OPT_COUNT] = {
 std::atomic<int> g_opt[X3D_OPT_COUNT];
 std::once_flag g_opt_once;
 
-int opt_initial(const OptDef& d) {
+bool opt_valid(int id, int v);
+// initial value of an option: its default, or the environment variable of the same meaning when that holds a value
+// x3d_set_option would accept (an out-of-range value -- X3D_DW_TH=0 would divide by zero in the tile geometry -- is
+// ignored with a warning on stderr)
+int opt_initial(int id) {
+    const OptDef& d = kOpts[id];
     const char* e = getenv(d.env);
     if (e == nullptr) return d.def;
-    return d.env_flag ? 1 : atoi(e);
+    const int v = d.env_flag ? 1 : atoi(e);
+    if (!opt_valid(id, v)) {
+        fprintf(stderr, "libx3dhip: %s=%s is out of range for option '%s': using the default %d\n", d.env, e, d.name, d.def);
+        return d.def;
+    }
+    return v;
 }
 void opt_init() {
-    for (int i = 0; i < X3D_OPT_COUNT; ++i) g_opt[i].store(opt_initial(kOpts[i]), std::memory_order_relaxed);
+    for (int i = 0; i < X3D_OPT_COUNT; ++i) g_opt[i].store(opt_initial(i), std::memory_order_relaxed);
 }
 int opt_find(const char* name) {
     if (name == nullptr) return -1;

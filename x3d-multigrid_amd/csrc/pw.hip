@@ -623,17 +623,16 @@ __device__ __forceinline__ void pack_item(int i, const float* __restrict__ w, fl
     const __bf16 h = (__bf16)v;
     __bf16* wq = reinterpret_cast<__bf16*>(wp + nf);
     wq[t] = h;
-    if (with_bf16 == 3) {           // three planes hi + mid + lo = all 24 significant bits (pw6 / pw7 / pwf / wgrad kernels)
-        const float r1 = v - (float)h;
-        const __bf16 m = (__bf16)r1;
-        wq[nq + t] = m;
-        wq[2 * nq + t] = (__bf16)(r1 - (float)m);
-    } else {                        // two planes (unused since ABI 6; kept for x3d_pw_pack_batch jobs that ask for it)
-        wq[nq + t] = (__bf16)(v - (float)h);
-    }
+    // ALWAYS three planes hi + mid + lo = all 24 significant bits (every consumer since ABI 6 -- pw6 / pw7 / pwf / the
+    // weight-gradient kernels -- reads the third plane; a job that still asked for two planes used to leave it
+    // uninitialised: ADVICE r03).  A two-term kernel reads hi and mid.
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    wq[nq + t] = m;
+    wq[2 * nq + t] = (__bf16)(r1 - (float)m);
 }
 
-// planes: 2 (transposed packs: hi, lo) or 3 (forward packs: hi, mid, lo)
+// planes: 3 (hi, mid, lo) in both orientations since ABI 6
 static size_t pack_items(int K, int M, int planes) {
     const size_t mt = cdiv(M, 16);
     return mt * cdiv(K, 16) * 256 + (planes ? mt * cdiv(K, 32) * 512 : 0);

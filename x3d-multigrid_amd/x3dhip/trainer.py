@@ -7,7 +7,6 @@ same shape on its share of the batch, gradients are summed with one bucketed all
 the flat buffer (15.18 MB fp32 for X3D-M) and divided by the world size inside the fused SGD
 kernel; BN statistics stay local to the rank (DataParallel semantics).
 """
-import os
 import weakref
 
 import torch
@@ -64,11 +63,12 @@ class GradReducer:
     backward pass is split around them, the early buckets travel over xGMI while the remaining
     backward kernels run.  The division by the world size happens in the fused SGD kernel."""
 
-    def __init__(self, flat_grad, buckets, world_size, process_group=None):
+    def __init__(self, flat_grad, buckets, world_size, process_group=None, force_collectives=False):
         self.flat_grad, self.buckets, self.world, self.pg = flat_grad, buckets, world_size, process_group
-        # X3D_FORCE_COLLECTIVES=1: issue the all-reduces on a one-rank group too (a sum over one rank is the identity) --
-        # how the RCCL path (backend "nccl") is exercised on a single-GPU box (tests/test_train_gpu.py)
-        self.active = world_size > 1 or (process_group is not None and os.environ.get("X3D_FORCE_COLLECTIVES") == "1")
+        # force_collectives: issue the all-reduces on a one-rank group too (a sum over one rank is the identity) -- how
+        # the RCCL path (backend "nccl") is exercised on a single-GPU box (tests/test_train_gpu.py)
+        self.force_collectives = bool(force_collectives)
+        self.active = world_size > 1 or (process_group is not None and self.force_collectives)
         self.stream = torch.cuda.Stream() if (self.active and flat_grad.is_cuda) else None
 
     def buffers_like(self):
@@ -114,8 +114,13 @@ class Trainer:
     owns the whole training step."""
 
     def __init__(self, model, lr, momentum=0.9, weight_decay=5e-5, process_group=None, world_size=1,
-                 use_graph=False, num_steps_per_update=1):
+                 use_graph=False, num_steps_per_update=1, overlap=True, force_split=False, force_collectives=False):
+        """overlap: multi-rank steps are captured as two graphs around the first gradient bucket (False: single graph,
+        all-reduce after the whole backward); force_split: the two-graph form on a single rank too (tests);
+        force_collectives: all-reduce on a one-rank process group (the single-GPU RCCL test).  Round 4: constructor
+        arguments -- nothing in this module reads the environment."""
         self.model = model
+        self.overlap, self.force_split = bool(overlap), bool(force_split)
         self.fp = FlatParams(model)
         # gradient accumulation (train_x3d_kinetics_multigrid.py:119,267-273): every train_step is one micro-batch with
         # loss / num_steps_per_update; the parameters move on every num_steps_per_update-th call
@@ -133,7 +138,8 @@ class Trainer:
         self._graphs = {}
         _TRAINERS.add(self)
         model._direct_grads = True      # engine writes parameter gradients straight into fp.grad
-        self.reducer = GradReducer(self.fp.grad, self.fp.head_first_buckets(model), world_size, process_group)
+        self.reducer = GradReducer(self.fp.grad, self.fp.head_first_buckets(model), world_size, process_group,
+                                   force_collectives=force_collectives)
 
     @property
     def lr(self):
@@ -263,7 +269,8 @@ class Trainer:
             if self.reducer.active:
                 # one exchange per optimizer step, on the accumulated gradient (no overlap with a backward pass here)
                 if self._acc_reducer is None:
-                    self._acc_reducer = GradReducer(self.accum, self.reducer.buffers_like(), self.world, self.pg)
+                    self._acc_reducer = GradReducer(self.accum, self.reducer.buffers_like(), self.world, self.pg,
+                                                    force_collectives=self.reducer.force_collectives)
                 self._acc_reducer.reduce()
             if pre_step is not None:
                 pre_step()
@@ -283,13 +290,13 @@ class Trainer:
 
     # -- data parallel: backward captured as two graphs around the first gradient bucket ---------
     def _overlap(self):
-        """Split capture is used for multi-rank runs (X3D_NO_OVERLAP=1 disables it; X3D_FORCE_SPLIT=1 enables it on a
+        """Split capture is used for multi-rank runs (Trainer(overlap=False) disables it; force_split=True enables it on a
         single rank for tests), task 'class', with the two-bucket layout."""
-        if os.environ.get("X3D_NO_OVERLAP") == "1" or len(self.reducer.buckets) != 2:
+        if not self.overlap or len(self.reducer.buckets) != 2:
             return False
         if getattr(self.model, "task", "class") != "class" or not self.model.training:
             return False
-        return self.world > 1 or os.environ.get("X3D_FORCE_SPLIT") == "1"
+        return self.world > 1 or self.force_split
 
     def _fwd_bwd_late(self, x, y):
         """Graph A: zero grads, forward, loss, head backward, trunk backward of conv5 / layer4 / layer3."""
