@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define X3D_ABI_VERSION 6
+#define X3D_ABI_VERSION 7
 
 #define X3D_OK 0
 #define X3D_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
@@ -301,6 +301,16 @@ int x3d_bn_eval_coef(const float* running_mean, const float* running_var,
 int x3d_se_fwd(const float* coef, const float* nsum, int N, int C, int Wd, int count,
                const float* w1, const float* b1, const float* w2, const float* b2,
                float* coef_out, float* save_se, float* save_z, float* save_pool, void* stream);
+
+/* Training forward of a Bottleneck with SE: x3d_bn_fwd_finalize (bn2, x3d.py:151) and x3d_se_fwd (x3d.py:153-159) in ONE
+ * launch (ABI 7).  partial[N][C][tiles][2] are conv2's statistics tiles; outputs as the two calls: save[2][S][C],
+ * nsum[N][C], save_se / save_pool[N][C], save_z[N][Wd], running statistics updated, and coef_out[n][c] = bn2's
+ * {scale, shift} * se[n][c] (what conv3's prologue applies before its Swish).  C <= 1024, Wd <= 64. */
+int x3d_se_bn_fwd(const float* partial, int N, int C, int tiles, int S, int count,
+                  const float* gamma, const float* beta, float* running_mean, float* running_var,
+                  float momentum, float eps, int Wd, const float* w1, const float* b1, const float* w2,
+                  const float* b2, float* coef_out, float* save, float* nsum, float* save_se, float* save_z,
+                  float* save_pool, void* stream);
 
 /* BN backward finalisation.  partial[N][C][tiles][2] = {sum g, sum g*raw} per (n,c,tile) where
  * g is the gradient w.r.t. the BN+affine output.  Produces

@@ -129,6 +129,39 @@ def test_pw_fwd(case):
         assert _rel(st[..., 1], (y_ref ** 2).sum(dim=(2, 3, 4))) < 5 * TOL
 
 
+# (N, Cin, Cout, T, H, W, act): the stage 3-4 layers the persistent producer / consumer kernel takes (K <= 224), with tail
+# tiles (P % 32 != 0), M not a multiple of 16, K not a multiple of 32, two M blocks (27 tiles), one tile per wave and two
+P8_CASES = [(8, 96, 216, 16, 14, 14, 0), (8, 216, 96, 16, 14, 14, 2), (8, 192, 432, 16, 7, 7, 0), (2, 96, 216, 4, 10, 10, 1),
+            (2, 216, 96, 4, 10, 10, 2), (3, 72, 162, 4, 10, 10, 0), (2, 162, 100, 5, 6, 6, 2), (2, 192, 432, 4, 5, 5, 0),
+            (1, 64, 96, 1, 2, 2, 1), (2, 128, 280, 4, 7, 7, 2), (5, 200, 120, 3, 6, 10, 0)]
+
+
+@pytest.mark.parametrize("case", P8_CASES)
+@pytest.mark.parametrize("grid", [0, 3, 40])
+def test_pw_fwd_persistent_kernel_is_bitwise_the_whole_k_kernel(case, grid):
+    """pw8_kernel (round 4: persistent, producer / consumer waves, double-buffered LDS, resident A fragments) against
+    pw6_kernel (option no_pw8) on the same inputs: y and the statistics tiles BITWISE equal (same products, same
+    accumulation order), for the default grid (one workgroup per CU) and for 3 / 40 workgroups (up to hundreds of items
+    per workgroup: the item loop, the buffer parity and the odd / even iteration tails)."""
+    from x3dhip import _lib, ops
+    dev = _dev()
+    N, Ci, Co, T, H, W, act = case
+    x = _g(N, Ci, T, H, W, seed=1).float().to(dev)
+    w = (_g(Co, Ci, seed=2) / np.sqrt(Ci)).float().to(dev)
+    pre = torch.stack([1 + 0.2 * _g(N, Ci, seed=3), 0.3 * _g(N, Ci, seed=4)], -1).float().contiguous().to(dev) if act else None
+    wp = ops.pw_pack(w)
+    with _lib.options(no_pw8=1):
+        y0, p0 = ops.pw_fwd(x, w, pre=pre, pre_act=act, wp=wp)
+        k0 = _lib.last_kernel()
+    with _lib.options(pw8_grid=grid):
+        y1, p1 = ops.pw_fwd(x, w, pre=pre, pre_act=act, wp=wp)
+        k1 = _lib.last_kernel()
+    torch.cuda.synchronize()
+    assert k0 == "pw6_kernel" and k1 == "pw8_kernel", (k0, k1)
+    assert torch.equal(y1, y0)
+    assert torch.equal(p1, p0)
+
+
 def _terms(terms):
     """Backward GEMM operand split for the duration of a test: 3 bf16 terms (default, fp32 level) or 2 (~2^-16)."""
     from x3dhip import _lib
@@ -529,6 +562,64 @@ def test_dw333_fwd_stats_equals_finalize_then_conv(case, S):
         assert _rel(rm_b, rm_a) < 1e-6 and _rel(rv_b, rv_a) < 1e-6
         assert _rel(y, y_ref) < 1e-5
         assert _rel(part.double().sum(2), p_ref.double().sum(2)) < 1e-5
+
+
+# (N, C, Wd, tiles, S): the SE blocks of X3D-M (54 / 108 / 216 / 432 channels, widths 8 / 8 / 16 / 32), the large-batch
+# multigrid shapes (N = 64 / 128 with 8 splits), XL widths (162 -> 16, 630 -> 40: Wd % 4 == 0 and a 3-unit-per-wave form),
+# an odd width (scalar fc2 loads), C = 1024
+SE_BN_CASES = [(8, 54, 8, 4, 1), (8, 108, 8, 2, 1), (8, 216, 16, 2, 1), (8, 432, 32, 2, 1), (2, 432, 32, 1, 2),
+               (64, 54, 8, 1, 8), (128, 216, 16, 1, 8), (16, 108, 8, 3, 2), (4, 162, 16, 2, 1), (4, 630, 40, 1, 2),
+               (2, 306, 20, 5, 1), (3, 70, 7, 2, 3), (2, 1024, 64, 1, 1)]
+
+
+@pytest.mark.parametrize("case", SE_BN_CASES)
+def test_elementwise_se_bn_fwd_equals_finalize_then_se(case):
+    """x3d_se_bn_fwd (round 4: bn2's finalize + the SE branch in one launch) against the two launches it replaces
+    (x3d_bn_fwd_finalize + x3d_se_fwd) and against an fp64 evaluation of x3d.py:47-58,153-159 on the same partial sums."""
+    from x3dhip import ops
+    dev = _dev()
+    N, C, Wd, tiles, S = case
+    count = 3136
+    sp = torch.stack([_g(N, C, tiles, seed=21) * 30, 800 + _g(N, C, tiles, seed=22).abs() * 400], -1).float().to(dev)
+    gamma = (1 + 0.2 * _g(C, seed=23)).float().to(dev)
+    beta = (0.3 * _g(C, seed=24)).float().to(dev)
+    w1 = (_g(Wd, C, seed=25) / C ** 0.5).float().to(dev)
+    b1 = (0.1 * _g(Wd, seed=26)).float().to(dev)
+    w2 = (_g(C, Wd, seed=27) / Wd ** 0.5).float().to(dev)
+    b2 = (0.1 * _g(C, seed=28)).float().to(dev)
+    rm0 = (0.1 * _g(S, C, seed=29)).float().to(dev)
+    rv0 = (1 + 0.1 * _g(S, C, seed=30).abs()).float().to(dev)
+    rm_a, rv_a, rm_b, rv_b = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
+    coef, save_a, nsum_a = ops.bn_fwd_finalize(sp, S, count, gamma, beta, rm_a, rv_a, 0.1, 1e-5, want_nsum=True)
+    ce_a, se_a, z_a, pool_a = ops.se_fwd(coef, nsum_a, count, w1, b1, w2, b2)
+    ce_b, save_b, nsum_b, se_b, z_b, pool_b = ops.se_bn_fwd(sp, S, count, gamma, beta, rm_b, rv_b, w1, b1, w2, b2, 0.1, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(save_b, save_a) and torch.equal(nsum_b, nsum_a)          # fp64 sums of fp32 terms: exact either way
+    assert torch.equal(rm_b, rm_a) and torch.equal(rv_b, rv_a)
+    assert torch.equal(pool_b, pool_a)
+    for a, b in ((z_a, z_b), (se_a, se_b), (ce_a, ce_b)):                        # fc1's summation order differs
+        assert _rel(b, a) < 2e-6
+    # fp64 truth
+    d = sp.double().cpu().sum(2)                                                  # [N, C, 2]
+    g64, b64 = gamma.double().cpu(), beta.double().cpu()
+    ref_ce = torch.empty(N, C, 2, dtype=torch.float64)
+    ref_se = torch.empty(N, C, dtype=torch.float64)
+    for j in range(S):
+        idx = torch.arange(j, N, S)
+        cnt = count * len(idx)
+        mean = d[idx, :, 0].sum(0) / cnt
+        var = (d[idx, :, 1].sum(0) / cnt - mean * mean).clamp_min(0)
+        invstd = 1 / torch.sqrt(var + 1e-5)
+        sc, sh = g64 * invstd, b64 - mean * g64 * invstd
+        pool = sc * d[idx, :, 0] / count + sh                                     # [ns, C]
+        z = torch.relu(pool @ w1.double().cpu().t() + b1.double().cpu())
+        se = torch.sigmoid(z @ w2.double().cpu().t() + b2.double().cpu())
+        ref_se[idx] = se
+        ref_ce[idx, :, 0] = sc * se
+        ref_ce[idx, :, 1] = sh * se
+        assert _rel(save_b[0, j], mean) < 1e-6 and _rel(save_b[1, j], invstd) < 1e-6
+    assert _rel(se_b, ref_se) < 2e-6
+    assert _rel(ce_b, ref_ce) < 2e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 4, 16, 16), (1, 3, 3, 15, 11), (1, 3, 2, 64, 64), (2, 3, 4, 158, 158)])

@@ -56,6 +56,8 @@ const OptDef kOpts[X3D_OPT_COUNT] = {
     /* X3D_OPT_PW6_MIN_M      */ {"pw6_min_m", "X3D_PW6_MIN_M", 96, 0},
     /* X3D_OPT_PW_TWO_TILES_K */ {"pw_two_tiles_k", "X3D_PW_TWO_TILES_K", 320, 0},
     /* X3D_OPT_DW_TSPLIT_WGS_FWD */ {"dw_tsplit_wgs_fwd", "X3D_DW_TSPLIT_WGS_FWD", 512, 0},
+    /* X3D_OPT_NO_PW8         */ {"no_pw8", "X3D_NO_PW8", 0, 1},
+    /* X3D_OPT_PW8_GRID       */ {"pw8_grid", "X3D_PW8_GRID", 0, 0},
 };
 std::atomic<int> g_opt[X3D_OPT_COUNT];
 std::once_flag g_opt_once;
@@ -87,6 +89,7 @@ bool opt_valid(int id, int v) {
     switch (id) {
         case X3D_OPT_FB_GRID: case X3D_OPT_PW_PGRID: case X3D_OPT_WG_CAP: case X3D_OPT_STEM_WG_CAP: return v >= 1 && v <= 65535;
         case X3D_OPT_PW_NT4_MIN: case X3D_OPT_DW_TSPLIT_WGS: case X3D_OPT_DW_TSPLIT_WGS_FWD: return v >= 0;
+        case X3D_OPT_PW8_GRID: return v >= 0 && v <= 65535;
         case X3D_OPT_DW_TH: case X3D_OPT_DW_CPB_MAX: return v >= 1 && v <= 16;
         case X3D_OPT_WG_CPW: return v >= 1 && v <= 4096;
         case X3D_OPT_PW6_MIN_M: case X3D_OPT_PW_TWO_TILES_K: return v >= 16 && v <= 4096;
@@ -99,6 +102,19 @@ bool opt_valid(int id, int v) {
 int x3d_opt(int id) {
     std::call_once(g_opt_once, opt_init);
     return g_opt[id].load(std::memory_order_relaxed);
+}
+
+// CUs of the current device (cached per device ordinal: the library may serve several devices from several threads)
+int x3d_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 
 extern "C" int x3d_set_option(const char* name, int value) {

@@ -277,6 +277,136 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ c
 }
 
 // ------------------------------------------------------------------------------------
+// Round 4: BN2's training finalize AND the SE branch in ONE launch (x3d.py:151-159 behind SubBatchNorm3d.forward :47-58).
+// bn_fwd_fused_kernel (workgroup per channel) + se_fwd_kernel (workgroup per sample, 256 threads, five serial memory round
+// trips: coefficients, two fc1 rounds, fc2) were two dependent launches of 4.8 + 6-12 us for microseconds of arithmetic;
+// every dependent launch of the replayed graph costs ~4.7 us whatever it does (profiles/r04/a_chain.txt).
+// Workgroup = sample n, 1024 threads, thread = channel: each workgroup reduces the statistics of ITS BN split redundantly
+// (the channelwise conv leaves 1-4 tile pairs per (sample, channel): N/S x tiles x 8 B per thread) in fp64, fixed order --
+// every workgroup of a split computes bitwise the same mean / invstd; the split's first sample publishes them and updates
+// the running statistics.  All weights (fc1 rows for this wave's hidden units, fc2 row of this thread's channel) are
+// requested in front of the statistics loads: ONE exposed memory round trip, then LDS / DPP arithmetic only.
+// UPW: hidden units per wave (Wd <= 16 UPW); CPL: channels per lane of an fc1 row (C <= 64 CPL).
+// ------------------------------------------------------------------------------------
+struct SeBnArgs {
+    const float* partial; const float* gamma; const float* beta; float* rmean; float* rvar;
+    const float* w1; const float* b1; const float* w2; const float* b2;
+    float* coef_out; float* save; float* nsum; float* save_se; float* save_z; float* save_pool;
+    int N, C, tiles, S, count, Wd;
+    float momentum, eps;
+};
+
+template <int UPW, int CPL>
+__global__ __launch_bounds__(1024) void se_bn_fwd_kernel(const SeBnArgs A) {
+    __shared__ float pool[SE_MAXC];
+    __shared__ float z[SE_MAXW];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = A.C, Wd = A.Wd, S = A.S, tiles = A.tiles;
+    const int j = n % S, ns = A.N / S;
+    const bool cv = tid < C;
+    const int c = cv ? tid : C - 1;                          // clamped: no load under a lane branch
+    // ---- (1) weights: independent of the statistics, requested first
+    float w1r[UPW][CPL];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int u = min(wave + 16 * i, Wd - 1);
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) w1r[i][k] = A.w1[(size_t)u * C + min(lane + 64 * k, C - 1)];
+    }
+    float w2r[16 * UPW];
+    if ((Wd & 3) == 0) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4 * UPW; ++q4) {
+            const float4 v = *reinterpret_cast<const float4*>(A.w2 + (size_t)c * Wd + min(4 * q4, Wd - 4));
+            w2r[4 * q4] = v.x; w2r[4 * q4 + 1] = v.y; w2r[4 * q4 + 2] = v.z; w2r[4 * q4 + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < 16 * UPW; ++w) w2r[w] = A.w2[(size_t)c * Wd + min(w, Wd - 1)];
+    }
+    const float b2c = A.b2[c], gm = A.gamma[c], bt = A.beta[c];
+    // ---- (2) statistics of this sample's split: row sums per sample (over its tiles), then over the samples, fp64
+    // (fp64 sums of fp32 tile sums: exact as long as the terms' exponents span < 2^29, so the grouping -- tiles outer,
+    // samples inner here; per-sample rows first in bn_fwd_fused_kernel -- does not show in the result)
+    double s1 = 0.0, s2 = 0.0, own = 0.0;
+    for (int m0 = 0; m0 < ns; m0 += 8) {
+        for (int t = 0; t < tiles; ++t) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int nn = j + min(m0 + u, ns - 1) * S;
+                v[u] = *reinterpret_cast<const float2*>(A.partial + (((size_t)nn * C + c) * tiles + t) * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (m0 + u < ns) {
+                    s1 += (double)v[u].x; s2 += (double)v[u].y;
+                    if (j + (m0 + u) * S == n) own += (double)v[u].x;
+                }
+            }
+        }
+    }
+    // ---- (3) BN2 coefficients (same arithmetic as bn_fwd_fused_kernel), pooled BN output of this sample
+    const double cnt = (double)A.count * (double)ns;
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)A.eps);
+    const float sc = (float)((double)gm * invstd);
+    const float sh = (float)((double)bt - mean * (double)gm * invstd);
+    float p = 0.f;
+    if (cv) {
+        if (n == j) {                                    // first sample of the split publishes its statistics
+            A.save[(size_t)j * C + c] = (float)mean;
+            A.save[(size_t)(S + j) * C + c] = (float)invstd;
+            if (A.rmean != nullptr) {
+                const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+                A.rmean[(size_t)j * C + c] = (float)((1.0 - A.momentum) * A.rmean[(size_t)j * C + c] + A.momentum * mean);
+                A.rvar[(size_t)j * C + c] = (float)((1.0 - A.momentum) * A.rvar[(size_t)j * C + c] + A.momentum * unb);
+            }
+        }
+        const float nsf = (float)own;
+        A.nsum[(size_t)n * C + c] = nsf;
+        p = fmaf(sc, nsf / (float)A.count, sh);
+        A.save_pool[(size_t)n * C + c] = p;
+    }
+    pool[tid] = p;                                       // (zeros beyond C: the fc1 rows are summed over 64 CPL slots)
+    __syncthreads();
+    // ---- (4) fc1 + ReLU: wave w owns hidden units w, w + 16, ...
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int u = wave + 16 * i;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int cc = lane + 64 * k;
+            acc = fmaf(cc < C ? w1r[i][k] : 0.f, pool[cc & (SE_MAXC - 1)], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0 && u < Wd) {
+            float t = acc + A.b1[u];
+            t = t > 0.f ? t : 0.f;
+            z[u] = t;
+            A.save_z[(size_t)n * Wd + u] = t;
+        }
+    }
+    __syncthreads();
+    // ---- (5) fc2 + sigmoid, gate folded into the coefficients conv3 applies on load
+    float s = b2c;
+#pragma unroll
+    for (int w = 0; w < 16 * UPW; ++w) {
+        if (w < Wd) s = fmaf(w2r[w], z[w], s);
+    }
+    if (cv) {
+        const float se = sigmoidf_(s);
+        A.save_se[(size_t)n * C + c] = se;
+        A.coef_out[((size_t)n * C + c) * 2] = sc * se;
+        A.coef_out[((size_t)n * C + c) * 2 + 1] = sh * se;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // BN backward finalize (thread per channel).  dsum[n][c] = {sum g, sum g*raw}.
 // extra (optional, SE variant): per-(n,c) arrays modifying the upstream gradient
 //   g_full = se[n,c]*g + dpool[n,c]/count
@@ -835,6 +965,40 @@ extern "C" int x3d_se_fwd(const float* coef, const float* nsum, int N, int C, in
     X3D_CHECK_ARG(N > 0 && C > 0 && C <= SE_MAXC && Wd > 0 && Wd <= SE_MAXW && count > 0);
     hipLaunchKernelGGL(se_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, coef, nsum, C, Wd, count, w1, b1,
                        w2, b2, coef_out, save_se, save_z, save_pool);
+    X3D_LAUNCH_CHECK();
+    return X3D_OK;
+}
+
+template <int UPW>
+static void se_bn_fwd_launch(const SeBnArgs& A, hipStream_t s) {
+    const int cpl = cdiv(A.C, 64);
+    if (cpl <= 2) hipLaunchKernelGGL((se_bn_fwd_kernel<UPW, 2>), dim3(A.N), dim3(1024), 0, s, A);
+    else if (cpl <= 4) hipLaunchKernelGGL((se_bn_fwd_kernel<UPW, 4>), dim3(A.N), dim3(1024), 0, s, A);
+    else if (cpl <= 8) hipLaunchKernelGGL((se_bn_fwd_kernel<UPW, 8>), dim3(A.N), dim3(1024), 0, s, A);
+    else hipLaunchKernelGGL((se_bn_fwd_kernel<UPW, 16>), dim3(A.N), dim3(1024), 0, s, A);
+}
+
+extern "C" int x3d_se_bn_fwd(const float* partial, int N, int C, int tiles, int S, int count, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                             int Wd, const float* w1, const float* b1, const float* w2, const float* b2,
+                             float* coef_out, float* save, float* nsum, float* save_se, float* save_z,
+                             float* save_pool, void* stream) {
+    X3D_CHECK_ARG(partial && gamma && beta && w1 && b1 && w2 && b2 && coef_out && save && nsum && save_se && save_z && save_pool);
+    X3D_CHECK_ARG(N > 0 && C > 0 && C <= SE_MAXC && Wd > 0 && Wd <= SE_MAXW && tiles > 0 && S > 0 && count > 0);
+    if (N % S != 0) {
+        x3d_set_error("split BN needs batch %% num_splits == 0 (got N=%d, splits=%d; x3d.py:50)", N, S);
+        return X3D_EINVAL;
+    }
+    SeBnArgs A;
+    A.partial = partial; A.gamma = gamma; A.beta = beta; A.rmean = running_mean; A.rvar = running_var;
+    A.w1 = w1; A.b1 = b1; A.w2 = w2; A.b2 = b2; A.coef_out = coef_out; A.save = save; A.nsum = nsum;
+    A.save_se = save_se; A.save_z = save_z; A.save_pool = save_pool;
+    A.N = N; A.C = C; A.tiles = tiles; A.S = S; A.count = count; A.Wd = Wd; A.momentum = momentum; A.eps = eps;
+    hipStream_t s = (hipStream_t)stream;
+    if (Wd <= 16) se_bn_fwd_launch<1>(A, s);
+    else if (Wd <= 32) se_bn_fwd_launch<2>(A, s);
+    else se_bn_fwd_launch<4>(A, s);
+    x3d_note_kernel("se_bn_fwd_kernel");
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

@@ -35,9 +35,12 @@ enum X3DOpt {
     X3D_OPT_PW6_MIN_M,        // whole-K forward kernel pw6: smallest output-channel count it takes                96
     X3D_OPT_PW_TWO_TILES_K,   // whole-K kernels: padded K from which a wave takes two M tiles of one staged tile  320
     X3D_OPT_DW_TSPLIT_WGS_FWD,  // the same threshold for the forward channelwise kernel (14 x 14 planes: 16.9 -> 14.7 us)  512
+    X3D_OPT_NO_PW8,           // round 4: non-persistent pw6 / pw7 instead of the producer / consumer kernels pw8 / pw9  0
+    X3D_OPT_PW8_GRID,         // workgroups of the persistent producer / consumer kernels (0 = one per CU)           0
     X3D_OPT_COUNT
 };
 int x3d_opt(int id);
+int x3d_cu_count();          // CUs of the current device (api.hip)
 
 #define X3D_CHECK_ARG(cond)                                                       \
     do {                                                                          \

@@ -227,6 +227,224 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
 
 
 // ---------------------------------------------------------------------------------------
+// Round 4: PERSISTENT producer / consumer form of pw6_kernel (same arithmetic, same results bit for bit).
+//
+// What bounded pw6: a workgroup's life is one dependent chain -- start 1.0 us, loads 0.4, staging
+// (activation + three-way split: VALU) 1.6, barrier 0.6, MFMA 2.2, stores 1.0 -- and a launch is 1.5-3 rounds of two such
+// workgroups per CU; the matrix pipes are busy 30 % of the time.  Here ONE workgroup per CU lives for the whole launch and
+// its waves are specialised:
+//   * waves 8-11 (producers) stage item i + 1: the whole K x 32 voxels of the next voxel tile requested one item ahead
+//     (two register sets), BN / SE / activation applied, split hi + mid + lo, written into the OTHER of two LDS buffers;
+//   * waves 0-7 (consumers) run the MFMA loop and the epilogue (statistics + stores) of item i from the first buffer:
+//     wave w owns the M tiles w, w + 8 (TPW = 2: both tiles share every B fragment read from LDS); their A fragments
+//     are loaded ONCE per launch and stay in registers when the layer's whole K fits (RES), else they come through a
+//     register ring from the L2-resident pack as in pw6;
+//   * one barrier per item: at barrier i the producers have filled buffer i & 1 and the consumers have finished reading
+//     buffer (i - 1) & 1, which is the one the producers fill next.  Both roles execute exactly `niter` barriers.
+// VALU staging and MFMA work of consecutive items overlap inside the workgroup, the start-up and the load latency are paid
+// once per launch, and 12 waves at 3 per SIMD leave 170 registers per lane for resident A fragments.
+// item = mb * VT8 + vt (voxel tile, M block): the M blocks of one voxel tile run on the same XCD (ids 8 | VT8 apart).
+// ---------------------------------------------------------------------------------------
+constexpr int P8_NT = 768;          // 8 consumer + 4 producer waves
+constexpr int P8_PROD0 = 512;       // first producer thread
+constexpr int P8_RP = 32;           // rows staged per pass by the 256 producer threads
+
+template <int KG, int TPW>
+struct P8Ring { static constexpr int RD = (KG * TPW <= 8) ? KG : 3; };
+
+template <int IN_AFF, int KG, int TPW>
+__global__ __launch_bounds__(P8_NT, 1) void pw8_kernel(const P6Args A) {
+    constexpr int RD = P8Ring<KG, TPW>::RD;               // A-fragment ring depth (k steps); RD == KG: the whole K
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = A.K, P = A.P, M = A.M;
+    const int kg32 = (K + 31) / 32, kg16 = (K + 15) / 16, Kp = kg32 * 32;
+    const size_t bufsz = (size_t)3 * Kp * P6_LD;
+    const int VT = A.N * A.tiles, VT8 = (VT + 7) & ~7;
+    const int items = VT8 * A.mblocks;
+    const int G = (int)gridDim.x;
+    const int niter = (items - (int)blockIdx.x + G - 1) / G;          // >= 1: the grid never exceeds the item count
+
+    if (wave >= 8) {
+        // ------------------------------------------------ producers
+        const int pt = tid - P8_PROD0;
+        const int c4 = (pt & 7) * 4, row0 = pt >> 3;
+        const int colE = c4 >> 1, colO = colE + 16;
+        float4 rxa[KG], rxb[KG];
+        float2 cfa[KG], cfb[KG];
+        bool pva = false, pvb = false;
+        auto issue = [&](int i, float4 (&rx)[KG], float2 (&cf)[KG], bool& pvv) {
+            const int it = (int)blockIdx.x + i * G;
+            const int mb = it / VT8;
+            const int vt = min(it - mb * VT8, VT - 1);
+            const int n = vt / A.tiles, tile = vt - n * A.tiles;
+            const int pt0 = tile * P6_BN;
+            const int pc = min(pt0 + c4, P - 4);
+            pvv = pt0 + c4 < P;
+            const float* xs = reinterpret_cast<const float*>(A.x) + (size_t)n * K * (size_t)P;
+            const float* cs = IN_AFF ? A.cin + (size_t)n * K * 2 : nullptr;
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                const unsigned k = (unsigned)min(row0 + P8_RP * j, K - 1);
+                rx[j] = *reinterpret_cast<const float4*>(xs + (size_t)k * (unsigned)P + (unsigned)pc);
+                if (IN_AFF) cf[j] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cs) + k * 8u);
+            }
+        };
+        auto stage = [&](int i, const float4 (&rx)[KG], const float2 (&cf)[KG], bool pvv) {
+            __bf16* Xh = lds6 + (size_t)(i & 1) * bufsz;
+            __bf16* Xm = Xh + (size_t)Kp * P6_LD;
+            __bf16* Xl = Xm + (size_t)Kp * P6_LD;
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                const int row = row0 + P8_RP * j;
+                if (row < Kp) {
+                    const bool ok = pvv && row < K;
+                    float v[4] = {rx[j].x, rx[j].y, rx[j].z, rx[j].w};
+                    if (IN_AFF) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_fwd(fmaf(cf[j].x, v[e], cf[j].y), A.in_act);
+                    }
+                    float xs[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xs[e] = ok ? v[e] : 0.f;
+                    unsigned hE, mE, lE, hO, mO, lO;               // pairs (0, 2) and (1, 3): x3d_split3_pair, common.h
+                    x3d_split3_pair(xs[0], xs[2], hE, mE, lE);
+                    x3d_split3_pair(xs[1], xs[3], hO, mO, lO);
+                    *reinterpret_cast<bf16x2*>(&Xh[row * P6_LD + colE]) = __builtin_bit_cast(bf16x2, hE);
+                    *reinterpret_cast<bf16x2*>(&Xh[row * P6_LD + colO]) = __builtin_bit_cast(bf16x2, hO);
+                    *reinterpret_cast<bf16x2*>(&Xm[row * P6_LD + colE]) = __builtin_bit_cast(bf16x2, mE);
+                    *reinterpret_cast<bf16x2*>(&Xm[row * P6_LD + colO]) = __builtin_bit_cast(bf16x2, mO);
+                    *reinterpret_cast<bf16x2*>(&Xl[row * P6_LD + colE]) = __builtin_bit_cast(bf16x2, lE);
+                    *reinterpret_cast<bf16x2*>(&Xl[row * P6_LD + colO]) = __builtin_bit_cast(bf16x2, lO);
+                }
+            }
+        };
+        issue(0, rxa, cfa, pva);
+        for (int i = 0; i < niter; i += 2) {
+            if (i + 1 < niter) issue(i + 1, rxb, cfb, pvb);
+            stage(i, rxa, cfa, pva);
+            __syncthreads();                                         // barrier i: buffer i & 1 is full
+            if (i + 1 < niter) {
+                if (i + 2 < niter) issue(i + 2, rxa, cfa, pva);
+                stage(i + 1, rxb, cfb, pvb);
+                __syncthreads();                                     // barrier i + 1
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- consumers
+    const int q = lane >> 4, r = lane & 15;
+    const int mtiles = (M + 15) / 16;
+    const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
+    const size_t plane = (size_t)mtiles * kg32 * 512;
+    const int tr_off = (8 * q + (r >> 2)) * P6_LD + 4 * (r & 3);
+    const bool resident = (RD == KG) && A.mblocks == 1;              // this wave's tiles never change: fetch A once
+    bf16x8 ah[TPW][RD], am[TPW][RD], al[TPW][RD];
+    const __bf16* wa[TPW];
+    bool tok[TPW];
+    int mt[TPW];
+    auto set_tiles = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int t = wave + 8 * j;
+            tok[j] = t < A.mt_run && mb * A.mt_run + t < mtiles;
+            mt[j] = min(mb * A.mt_run + t, mtiles - 1);              // clamped: a duplicate is never stored
+            wa[j] = wq + ((size_t)mt[j] * kg32 * 64 + lane) * 8;     // + s * 512 per k step, + plane per plane
+        }
+    };
+    auto fetch_a = [&](int j, int s, bf16x8& h, bf16x8& m, bf16x8& l) {
+        const int sc = min(s, kg32 - 1);
+        h = *reinterpret_cast<const bf16x8*>(wa[j] + (size_t)sc * 512);
+        m = *reinterpret_cast<const bf16x8*>(wa[j] + (size_t)sc * 512 + plane);
+        l = *reinterpret_cast<const bf16x8*>(wa[j] + (size_t)sc * 512 + 2 * plane);
+    };
+    auto tr_frag = [&](const __bf16* pl, int s, int h2) -> bf16x8 {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const __bf16* p0 = pl + 32 * s * P6_LD + tr_off + 16 * h2;
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * P6_LD));
+        return cat8_(v0, v1);
+    };
+    int cur_mb = -1;
+    for (int i = 0; i < niter; ++i) {
+        const int it = (int)blockIdx.x + i * G;
+        const int mb = it / VT8;
+        const int vt0 = it - mb * VT8;
+        const bool valid = vt0 < VT;
+        const int vt = min(vt0, VT - 1);
+        const int n = vt / A.tiles, tile = vt - n * A.tiles;
+        const int pt0 = tile * P6_BN;
+        if (!resident || i == 0) {
+            if (mb != cur_mb) { set_tiles(mb); cur_mb = mb; }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+#pragma unroll
+                for (int s = 0; s < RD; ++s) fetch_a(j, s, ah[j][s], am[j][s], al[j][s]);
+        }
+        __syncthreads();                                             // barrier i: buffer i & 1 is full
+        const __bf16* Xh = lds6 + (size_t)(i & 1) * bufsz;
+        const __bf16* Xm = Xh + (size_t)Kp * P6_LD;
+        const __bf16* Xl = Xm + (size_t)Kp * P6_LD;
+        f32x4 acc[TPW][2];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (tok[0]) {                                                // wave-uniform (tiles ascend with j: tok[1] implies tok[0])
+#pragma unroll
+            for (int s = 0; s < KG; ++s) {
+                if (s < kg32) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int slot = s % RD;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const bf16x8 bh = tr_frag(Xh, s, h2), bm = tr_frag(Xm, s, h2), bl = tr_frag(Xl, s, h2);
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j) {
+                            if (j == 0 || tok[j]) {                  // smallest terms first, as pw6_kernel
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j][slot], bh, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bl, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j][slot], bm, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j][slot], bh, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bm, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bh, acc[j][h2], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (RD < KG && s + RD < kg32) {                  // ring: the slot's next k step
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j) fetch_a(j, s + RD, ah[j][slot], am[j][slot], al[j][slot]);
+                    }
+                }
+            }
+            // ---- epilogue: lane (q, r) holds rows 4 q + e of a tile and voxels 2 r (acc[.][0]), 2 r + 1 (acc[.][1])
+            const int pl = pt0 + 2 * r;
+            const bool pv = valid && pl < P;                         // P even: both voxels or none
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (j == 0 || tok[j]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = mt[j] * 16 + 4 * q + e;
+                        const bool mv = m < M;
+                        const float v0 = pv ? acc[j][0][e] : 0.f, v1 = pv ? acc[j][1][e] : 0.f;
+                        if (mv && pv) *reinterpret_cast<float2*>(reinterpret_cast<float*>(A.y) + ((size_t)n * M + m) * (size_t)P + pl) = make_float2(v0, v1);
+                        if (A.partial != nullptr) {
+                            const float s1 = row16_sum(v0 + v1);
+                            const float s2 = row16_sum(fmaf(v0, v0, v1 * v1));
+                            if (r == 0 && mv && valid) {
+                                float* pp = A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2;
+                                pp[0] = s1; pp[1] = s2;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Data gradient of the same layers (ConvolutionBackward grad_input of conv1x1x1, x3d.py:98-103, fused with the BN backward
 // in front and the activation / residual backward behind it exactly as pw5_kernel in pw.hip): the whole-K item structure
 // above with dY = cb0*g + cb1*a + cb2 staged as TWO bf16 planes (hi + lo, 3 MFMA products: the backward kernels'
@@ -513,6 +731,41 @@ int x3d_pw6_launch(const void* x, const float* cin, const float* wp, void* y, fl
     do {                                                                                                       \
         if (npass <= 2) P6_GO(AFF, 2, MX_); else if (npass <= 4) P6_GO(AFF, 4, MX_); else P6_GO(AFF, 7, MX_);  \
     } while (0)
+    // round 4: the persistent producer / consumer form (fp32 storage, K <= 224: two LDS buffers of three planes each)
+    if (!x_bf && !y_bf && kp <= 224 && !x3d_opt(X3D_OPT_NO_PW8)) {
+        const int tpw = mtiles <= 8 ? 1 : 2;
+        A.mblocks = cdiv(mtiles, 8 * tpw);
+        A.mt_run = cdiv(mtiles, A.mblocks);
+        const int vt8 = (VT + 7) & ~7;
+        const int items = vt8 * A.mblocks;
+        int g = x3d_opt(X3D_OPT_PW8_GRID);
+        if (g <= 0) g = x3d_cu_count();
+        if (g > items) g = items;
+        const size_t lds8 = (size_t)2 * 3 * kp * P6_LD * sizeof(__bf16);
+        const int kg = kp / 32;
+#define P8_GO(AFF, KG_, TPW_)                                                                                       \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw8_kernel<AFF, KG_, TPW_>),                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 32 * KG_ * P6_LD * 2);     \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((pw8_kernel<AFF, KG_, TPW_>), dim3(g), dim3(P8_NT), lds8, s, A);                          \
+    } while (0)
+#define P8_KG(AFF, TPW_)                                                                                            \
+    do {                                                                                                            \
+        if (kg <= 3) P8_GO(AFF, 3, TPW_); else if (kg <= 4) P8_GO(AFF, 4, TPW_);                                     \
+        else if (kg <= 6) P8_GO(AFF, 6, TPW_); else P8_GO(AFF, 7, TPW_);                                             \
+    } while (0)
+        x3d_note_kernel("pw8_kernel");
+        if (cin) { if (tpw == 1) P8_KG(1, 1); else P8_KG(1, 2); }
+        else { if (tpw == 1) P8_KG(0, 1); else P8_KG(0, 2); }
+#undef P8_KG
+#undef P8_GO
+        X3D_LAUNCH_CHECK();
+        return X3D_OK;
+    }
     x3d_note_kernel("pw6_kernel");
     if (x_bf || y_bf) { if (cin) P6_PASS(1, true); else P6_PASS(0, true); }
     else if (cin) P6_PASS(1, false); else P6_PASS(0, false);

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx3dhip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "x3d_bn_fwd_finalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "x3d_bn_eval_coef": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P]),
     "x3d_se_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "x3d_se_bn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "x3d_bn_bwd_finalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "x3d_se_bn_bwd_finalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P,
                                     _P, _P, _P, _P, _P, _P, _P, _P, _P]),

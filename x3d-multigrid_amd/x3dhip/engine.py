@@ -141,6 +141,7 @@ class _Config:
         self.wgrad_overlap = env("X3D_WGRAD_OVERLAP", "0") == "1"
         self.side_stream = env("X3D_SIDE_STREAM") == "1" and env("X3D_NO_SIDE_STREAM") != "1"
         self.exp_skip_wgrad = env("X3D_EXP_SKIP_WGRAD") == "1"       # timing experiment only: gradients are wrong
+        self.no_se_merge = env("X3D_NO_SE_MERGE", "0") == "1"        # separate bn2 finalize + SE launches (round 3)
 
 
 cfg = _Config()
@@ -241,19 +242,27 @@ def _block_forward(blk, x_raw, x_coef, S, training, ctx, packs, wide=torch.float
                                want_stats=training or blk.has_se)
     P2 = a2[0, 0].numel()
     nsum2 = None
-    if training:
-        c2, s2, nsum2 = _bn_train(p2, blk.bn2, S, P2, want_nsum=blk.has_se)
-    else:
-        c2, s2 = _bn_eval(blk.bn2, N), None
-        if blk.has_se:
-            nsum2 = p2.sum(dim=2)[..., 0].contiguous()   # per-(n,c) sum of raw a2 (tiny tensor)
     se = None
-    if blk.has_se:
-        c2e, se_v, z, pool = ops.se_fwd(c2, nsum2, P2, _w2d(blk.fc1.weight), blk.fc1.bias.data,
-                                        _w2d(blk.fc2.weight), blk.fc2.bias.data)
+    if training and blk.has_se and not cfg.no_se_merge and blk.bn2.weight.shape[0] <= 1024:
+        # bn2's finalize and the SE branch in one launch (round 4)
+        bn2 = blk.bn2
+        c2e, s2, nsum2, se_v, z, pool = ops.se_bn_fwd(p2, S, P2, bn2.weight.data, bn2.bias.data, bn2.split_bn.running_mean,
+                                                      bn2.split_bn.running_var, _w2d(blk.fc1.weight), blk.fc1.bias.data,
+                                                      _w2d(blk.fc2.weight), blk.fc2.bias.data, BN_MOMENTUM, BN_EPS)
         se = dict(se=se_v, z=z, pool=pool, nsum=nsum2)
     else:
-        c2e = c2
+        if training:
+            c2, s2, nsum2 = _bn_train(p2, blk.bn2, S, P2, want_nsum=blk.has_se)
+        else:
+            c2, s2 = _bn_eval(blk.bn2, N), None
+            if blk.has_se:
+                nsum2 = p2.sum(dim=2)[..., 0].contiguous()   # per-(n,c) sum of raw a2 (tiny tensor)
+        if blk.has_se:
+            c2e, se_v, z, pool = ops.se_fwd(c2, nsum2, P2, _w2d(blk.fc1.weight), blk.fc1.bias.data,
+                                            _w2d(blk.fc2.weight), blk.fc2.bias.data)
+            se = dict(se=se_v, z=z, pool=pool, nsum=nsum2)
+        else:
+            c2e = c2
     a3, p3 = ops.pw_fwd(a2, w3, pre=c2e, pre_act=ACT_SWISH, want_stats=training, wp=packs.get(blk.conv3.weight))
     c3 = s3 = None
     if not training:

@@ -498,6 +498,24 @@ def se_fwd(coef, nsum, count, w1, b1, w2, b2):
     return coef_out, se, z, pool
 
 
+def se_bn_fwd(partial, S, count, gamma, beta, running_mean, running_var, w1, b1, w2, b2, momentum=0.1, eps=1e-5):
+    """bn_fwd_finalize (bn2) + se_fwd in one launch (training forward of a Bottleneck with SE, x3d.py:151-159).
+    Returns (coef_out, save, nsum, se, z, pool)."""
+    L = _lib.lib()
+    N, C, tiles, _ = partial.shape
+    Wd = w1.shape[0]
+    coef_out = _f((N, C, 2), partial)
+    save = _f((2, S, C), partial)
+    nsum = _f((N, C), partial)
+    se = _f((N, C), partial)
+    z = _f((N, Wd), partial)
+    pool = _f((N, C), partial)
+    check(L.x3d_se_bn_fwd(ptr(partial), N, C, tiles, S, count, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                          momentum, eps, Wd, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(coef_out), ptr(save), ptr(nsum),
+                          ptr(se), ptr(z), ptr(pool), _lib.stream()))
+    return coef_out, save, nsum, se, z, pool
+
+
 def bn_bwd_finalize(partial, S, count, gamma, save, dgamma=None, dbeta=None, accumulate=False):
     L = _lib.lib()
     N, C, tiles, _ = partial.shape
