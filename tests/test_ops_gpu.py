@@ -153,13 +153,67 @@ def test_pw_fwd_persistent_kernel_is_bitwise_the_whole_k_kernel(case, grid):
     with _lib.options(no_pw8=1):
         y0, p0 = ops.pw_fwd(x, w, pre=pre, pre_act=act, wp=wp)
         k0 = _lib.last_kernel()
-    with _lib.options(pw8_grid=grid):
+    with _lib.options(pw8_grid=grid, pw8_max_k=224):
         y1, p1 = ops.pw_fwd(x, w, pre=pre, pre_act=act, wp=wp)
         k1 = _lib.last_kernel()
     torch.cuda.synchronize()
     assert k0 == "pw6_kernel" and k1 == "pw8_kernel", (k0, k1)
     assert torch.equal(y1, y0)
     assert torch.equal(p1, p0)
+
+
+# (N, Cin, Cout, T, H, W): data gradient of conv Cin -> Cout (GEMM K = Cout <= 224, M = Cin)
+P9_CASES = [(8, 216, 96, 16, 14, 14), (8, 96, 216, 16, 14, 14), (8, 432, 192, 16, 7, 7), (2, 216, 96, 4, 10, 10),
+            (2, 96, 216, 4, 10, 10), (3, 162, 72, 4, 10, 10), (2, 100, 162, 5, 6, 6), (2, 432, 192, 4, 5, 5),
+            (1, 96, 64, 1, 2, 2), (2, 280, 128, 4, 7, 7), (5, 120, 200, 3, 6, 10)]
+
+
+@pytest.mark.parametrize("case", P9_CASES)
+@pytest.mark.parametrize("grid", [0, 3, 40])
+def test_pw_bwd_persistent_kernel_is_bitwise_the_whole_k_kernel(case, grid):
+    """pw9_kernel (round 4: persistent producer / consumer data gradient) against pw7_kernel (option no_pw8): dX and the
+    statistics tiles BITWISE equal in all three epilogue modes -- plain (downsample branch), activation backward with a
+    BN / SE prologue record (conv3), residual-add + ReLU backward with a dense and with a stride-2 addend (conv1)."""
+    from x3dhip import _lib, ops
+    dev = _dev()
+    N, Ci, Co, T, H, W = case
+    g = _g(N, Co, T, H, W, seed=1).float().to(dev)
+    a = _g(N, Co, T, H, W, seed=2).float().to(dev)
+    cb = torch.stack([1 + 0.2 * _g(N, Co, seed=3), 0.1 * _g(N, Co, seed=4), 0.05 * _g(N, Co, seed=5)], -1).float().contiguous().to(dev)
+    w = (_g(Co, Ci, seed=6) / np.sqrt(Co)).float().to(dev)
+    wpt = ops.pw_pack(w, transposed=True)
+    x = _g(N, Ci, T, H, W, seed=7).float().to(dev)
+    pre = torch.stack([1 + 0.2 * _g(N, Ci, seed=8), 0.3 * _g(N, Ci, seed=9)], -1).float().contiguous().to(dev)
+    res_out = torch.relu(_g(N, Ci, T, H, W, seed=10)).float().to(dev)
+    res_raw = _g(N, Ci, T, H, W, seed=11).float().to(dev)
+    add1 = _g(N, Ci, T, H, W, seed=12).float().to(dev)
+    add2 = _g(N, Ci, T, (H - 1) // 2 + 1, (W - 1) // 2 + 1, seed=13).float().to(dev)
+
+    def run():
+        outs = []
+        o, _ = ops.pw_bwd_data(g, a, cb, w, wpt=wpt)
+        outs += [o, _lib.last_kernel()]
+        o, p = ops.pw_bwd_data(g, a, cb, w, x=x, pre=pre, pre_act=2, wpt=wpt)
+        outs += [o, p]
+        o, p = ops.pw_bwd_data(g, a, cb, w, x=x, pre=pre, pre_act=1, addend=add1, wpt=wpt)
+        outs += [o, p]
+        o, p = ops.pw_bwd_data_res(g, a, cb, w, res_out, res_raw, wpt=wpt)
+        outs += [o, p]
+        o, p = ops.pw_bwd_data_res(g, a, cb, w, res_out, res_raw, addend=add1, wpt=wpt)
+        outs += [o, p]
+        o, p = ops.pw_bwd_data_res(g, a, cb, w, res_out, res_raw, addend=add2, addend_stride=2, wpt=wpt)
+        outs += [o, p]
+        torch.cuda.synchronize()
+        return outs
+
+    with _lib.options(no_pw8=1):
+        r0 = run()
+    with _lib.options(pw8_grid=grid, pw9_max_k=224):
+        r1 = run()
+    assert r0[1] == "pw7_kernel" and r1[1] == "pw9_kernel", (r0[1], r1[1])
+    for i, (u, v) in enumerate(zip(r0, r1)):
+        if i != 1:
+            assert torch.equal(u, v), i
 
 
 def _terms(terms):
@@ -620,6 +674,39 @@ def test_elementwise_se_bn_fwd_equals_finalize_then_se(case):
         assert _rel(save_b[0, j], mean) < 1e-6 and _rel(save_b[1, j], invstd) < 1e-6
     assert _rel(se_b, ref_se) < 2e-6
     assert _rel(ce_b, ref_ce) < 2e-6
+
+
+# (N, C, Wd, tiles, S): SE blocks of stages 3-4 at the multigrid shapes (98 / 25 / 13 / 7 statistics tiles per row), XL widths
+SE_BWD_CASES = [(8, 216, 16, 98, 1), (8, 432, 32, 25, 1), (16, 216, 16, 49, 2), (64, 432, 32, 7, 8), (2, 216, 16, 13, 2),
+                (4, 306, 20, 50, 1), (2, 630, 40, 25, 1), (3, 70, 7, 100, 3), (2, 1024, 64, 30, 1)]
+
+
+@pytest.mark.parametrize("case", SE_BWD_CASES)
+def test_elementwise_se_bwd_merged_sample_kernel_equals_the_two_launches(case):
+    """x3d_se_bn_bwd_finalize with the merged tile-reduction + per-sample SE backward kernel (round 4) against the same entry
+    point with option no_se_bwd_merge (reduce_tiles + se_bwd_sample launches): BN-backward coefficients, dgamma / dbeta and
+    the SE weight gradients agree to fp32 summation-order noise."""
+    from x3dhip import _lib, ops
+    dev = _dev()
+    N, C, Wd, tiles, S = case
+    count = 32 * tiles
+    part = torch.stack([_g(N, C, tiles, seed=31) * 0.3, _g(N, C, tiles, seed=32) * 2], -1).float().to(dev)
+    gamma = (1 + 0.2 * _g(C, seed=33)).float().to(dev)
+    beta = (0.3 * _g(C, seed=34)).float().to(dev)
+    save = torch.stack([0.2 * _g(S, C, seed=35), 0.5 + _g(S, C, seed=36).abs()], 0).float().contiguous().to(dev)
+    nsum = (_g(N, C, seed=37) * count * 0.3).float().to(dev)
+    w1 = (_g(Wd, C, seed=38) / C ** 0.5).float().to(dev)
+    w2 = (_g(C, Wd, seed=39) / Wd ** 0.5).float().to(dev)
+    se = torch.sigmoid(_g(N, C, seed=40)).float().to(dev)
+    z = torch.relu(_g(N, Wd, seed=41)).float().to(dev)
+    pool = _g(N, C, seed=42).float().to(dev)
+    with _lib.options(no_se_bwd_merge=1):
+        cb0, o0 = ops.se_bn_bwd_finalize(part, S, count, gamma, beta, save, nsum, w1, w2, se, z, pool)
+    cb1, o1 = ops.se_bn_bwd_finalize(part, S, count, gamma, beta, save, nsum, w1, w2, se, z, pool)
+    torch.cuda.synchronize()
+    assert _rel(cb1, cb0) < 2e-6
+    for k in o0:
+        assert _rel(o1[k], o0[k]) < 5e-6, k
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 4, 16, 16), (1, 3, 3, 15, 11), (1, 3, 2, 64, 64), (2, 3, 4, 158, 158)])

@@ -68,6 +68,18 @@ def main():
         c[1] += (e - s) / 1e3
         print("%4d %9.1f %7.2f gap %6.2f  %-10s %s" % (i, (s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, k, n), file=out)
         prev_end = e
+    # the 62 `__amd_rocclr_copyBuffer` per step execution of profiles/r03/h_kernel_stats.csv.  They are
+    # not nodes of the replayed graph: count them inside every window between two weight-pack launches (= one execution of
+    # the step: eager warm-up, capture, replay) and report which kind of window holds them.
+    copies = [i for i, r in enumerate(rows) if "copyBuffer" in r[0] or "copy_buffer" in r[0].lower()]
+    per_window = []
+    for w0, w1 in zip(packs[:-1], packs[1:]):
+        n_all = w1 - w0
+        n_cp = len([i for i in copies if w0 <= i < w1])
+        per_window.append((n_all, n_cp))
+    print("# __amd_rocclr_copyBuffer: %d in the whole trace (%d launches); per step window (launches, copies): %s"
+          % (len(copies), len(rows), " ".join("%d/%d" % w for w in per_window)), file=out)
+    print("# (windows with %d launches are graph replays; the larger ones are eager warm-up / capture executions)" % len(step), file=out)
     print("# per class:", file=out)
     for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         print("#   %-12s %4d launches %9.1f us" % (k, c, t), file=out)

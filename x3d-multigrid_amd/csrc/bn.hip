@@ -542,6 +542,120 @@ __global__ __launch_bounds__(256) void se_bwd_sample_kernel(
     }
 }
 
+// Round 4: reduce_tiles_kernel<2> + se_bwd_sample_kernel in ONE launch for the stage 3-4 blocks (98 / 25 statistics tiles per
+// row): workgroup = sample, 1024 threads.  (1) every weight the sample needs is requested first (fc2 row and fc1 column of
+// the thread's channel: 2 Wd registers); (2) TPR threads per channel row sum its tile pairs in fp64 (lane-strided, four
+// loads in flight, butterfly over the TPR lanes: fixed order) -> dsum[n][c] for se_tail_kernel and, through LDS, for
+// (3) dz2 = dL/d(fc2 pre-activation); (4) fc2 backward: products w2[c][u] * dz2[c] through an LDS image [16 units][C],
+// wave w sums unit w of each 16-unit round lane-strided (fixed order); (5) fc1 backward per channel from registers.
+// The old pair cost 4.8 + 6.5-16 us (se_bwd_sample_kernel: 256 threads, one memory round trip per 16 hidden units).
+struct SeBwdArgs {
+    const float* partial; double* dsum; const float* gamma; const float* beta; const float* save;
+    const float* w1; const float* w2; const float* save_se; const float* save_z;
+    float* dpool; float* dz2o; float* dz1o;
+    int C, S, Wd, tiles, tpr;
+};
+
+template <int UPW>
+__global__ __launch_bounds__(1024) void se_bwd_sample2_kernel(const SeBwdArgs A) {
+    __shared__ double dsl[2 * SE_MAXC];
+    __shared__ float dz1s[SE_MAXW];
+    __shared__ float prod[16][SE_MAXC];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = A.C, Wd = A.Wd, S = A.S, tiles = A.tiles, TPR = A.tpr;
+    const int j = n % S;
+    const bool cv = tid < C;
+    const int c = cv ? tid : C - 1;
+    // ---- (1) weights and per-channel constants of this thread's channel
+    float w2r[16 * UPW], w1r[16 * UPW];
+    if ((Wd & 3) == 0) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4 * UPW; ++q4) {
+            const float4 v = *reinterpret_cast<const float4*>(A.w2 + (size_t)c * Wd + min(4 * q4, Wd - 4));
+            w2r[4 * q4] = v.x; w2r[4 * q4 + 1] = v.y; w2r[4 * q4 + 2] = v.z; w2r[4 * q4 + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < 16 * UPW; ++w) w2r[w] = A.w2[(size_t)c * Wd + min(w, Wd - 1)];
+    }
+#pragma unroll
+    for (int w = 0; w < 16 * UPW; ++w) w1r[w] = A.w1[(size_t)min(w, Wd - 1) * C + c];
+    const double mean = A.save[(size_t)j * C + c], invstd = A.save[(size_t)(S + j) * C + c];
+    const double k = (double)A.gamma[c] * invstd, h = (double)A.beta[c] - mean * k;
+    const float sv = A.save_se[(size_t)n * C + c];
+    // ---- (2) tile sums of this sample's rows: TPR lanes per row (C * TPR <= 1024)
+    {
+        const int row = tid / TPR, l = tid - row * TPR;
+        const bool rv = row < C;
+        const float* p = A.partial + ((size_t)n * C + (rv ? row : 0)) * tiles * 2;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        int t = l;
+        for (; t + 3 * TPR < tiles; t += 4 * TPR) {
+            const float2 v0 = *reinterpret_cast<const float2*>(p + 2 * t);
+            const float2 v1 = *reinterpret_cast<const float2*>(p + 2 * (t + TPR));
+            const float2 v2 = *reinterpret_cast<const float2*>(p + 2 * (t + 2 * TPR));
+            const float2 v3 = *reinterpret_cast<const float2*>(p + 2 * (t + 3 * TPR));
+            a0 += (double)v0.x; b0 += (double)v0.y;
+            a1 += (double)v1.x; b1 += (double)v1.y;
+            a2 += (double)v2.x; b2 += (double)v2.y;
+            a3 += (double)v3.x; b3 += (double)v3.y;
+        }
+        for (; t < tiles; t += TPR) {
+            const float2 v = *reinterpret_cast<const float2*>(p + 2 * t);
+            a0 += (double)v.x;
+            b0 += (double)v.y;
+        }
+        double a = (a0 + a1) + (a2 + a3), b = (b0 + b1) + (b2 + b3);
+        for (int o = TPR >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (l == 0 && rv) {
+            dsl[2 * row] = a; dsl[2 * row + 1] = b;
+            A.dsum[((size_t)n * C + row) * 2] = a;
+            A.dsum[((size_t)n * C + row) * 2 + 1] = b;
+        }
+    }
+    __syncthreads();
+    // ---- (3) dL/d(fc2 pre-activation) of this channel (se_bwd_sample_kernel's arithmetic)
+    float dz2v = 0.f;
+    if (cv) {
+        const double d0 = dsl[2 * c], d1 = dsl[2 * c + 1];
+        const float dse = (float)(k * d1 + h * d0);
+        dz2v = dse * sv * (1.f - sv);
+        A.dz2o[(size_t)n * C + c] = dz2v;
+    }
+    // ---- (4) fc2 backward onto the hidden units, 16 units per round
+    for (int w0 = 0; w0 < Wd; w0 += 16) {
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            if (16 * i == w0) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) prod[u][tid] = cv ? w2r[16 * i + u] * dz2v : 0.f;
+            }
+        }
+        __syncthreads();
+        const int u = w0 + wave;                         // wave w: unit w0 + w
+        float acc = 0.f;
+        for (int cc = lane; cc < C; cc += 64) acc += prod[wave][cc];
+        acc = wave_sum(acc);
+        if (lane == 0 && u < Wd) {
+            const float zv = A.save_z[(size_t)n * Wd + u];
+            const float v = zv > 0.f ? acc : 0.f;
+            dz1s[u] = v;
+            A.dz1o[(size_t)n * Wd + u] = v;
+        }
+        __syncthreads();
+    }
+    // ---- (5) fc1 backward onto the pooled channel (same order as se_bwd_sample_kernel: w ascending)
+    if (cv) {
+        float sp = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16 * UPW; ++w) {
+            if (w < Wd) sp = fmaf(w1r[w], dz1s[w], sp);
+        }
+        A.dpool[(size_t)n * C + c] = sp;
+    }
+}
+
 // SE weight gradients: thread per (c, w) pair; sums over samples in order.
 __device__ __forceinline__ void se_wgrad_element(int i, int N, int C, int Wd, const float* __restrict__ dz2, const float* __restrict__ dz1,
                                 const float* __restrict__ save_z, const float* __restrict__ save_pool,
@@ -1037,9 +1151,24 @@ extern "C" int x3d_se_bn_bwd_finalize(const float* partial, int N, int C, int ti
     float* dpool = (float*)(dsum + (size_t)N * C * 2);
     float* dz2 = dpool + (size_t)N * C;
     float* dz1 = dz2 + (size_t)N * C;
-    hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
-    hipLaunchKernelGGL(se_bwd_sample_kernel, dim3(N), dim3(256), 0, s, dsum, C, S, Wd, gamma, beta, save, w1, w2,
-                       save_se, save_z, dpool, dz2, dz1);
+    // threads per row of the merged tile-reduction + per-sample kernel: the largest power of two with C * tpr <= 1024
+    int tpr = 1;
+    while (tpr < 16 && C * tpr * 2 <= 1024) tpr *= 2;
+    // (round 4) one launch instead of two where a thread sums at most 32 tile pairs (stages 3-4 of every model at the
+    // multigrid shapes: 98 / 25 tiles per row; the stage 1-2 rows have 392-1568 tiles and keep the all-CU reduction)
+    if (!x3d_opt(X3D_OPT_NO_SE_BWD_MERGE) && cdiv(tiles, tpr) <= 32) {
+        SeBwdArgs B;
+        B.partial = partial; B.dsum = dsum; B.gamma = gamma; B.beta = beta; B.save = save; B.w1 = w1; B.w2 = w2;
+        B.save_se = save_se; B.save_z = save_z; B.dpool = dpool; B.dz2o = dz2; B.dz1o = dz1;
+        B.C = C; B.S = S; B.Wd = Wd; B.tiles = tiles; B.tpr = tpr;
+        if (Wd <= 16) hipLaunchKernelGGL((se_bwd_sample2_kernel<1>), dim3(N), dim3(1024), 0, s, B);
+        else if (Wd <= 32) hipLaunchKernelGGL((se_bwd_sample2_kernel<2>), dim3(N), dim3(1024), 0, s, B);
+        else hipLaunchKernelGGL((se_bwd_sample2_kernel<4>), dim3(N), dim3(1024), 0, s, B);
+    } else {
+        hipLaunchKernelGGL(reduce_tiles_kernel<2>, dim3(cdiv(N * C, 4)), dim3(256), 0, s, partial, dsum, N * C, tiles);
+        hipLaunchKernelGGL(se_bwd_sample_kernel, dim3(N), dim3(256), 0, s, dsum, C, S, Wd, gamma, beta, save, w1, w2,
+                           save_se, save_z, dpool, dz2, dz1);
+    }
     const int nbw = cdiv(C * Wd, 256);
     hipLaunchKernelGGL(se_tail_kernel, dim3(nbw + (64 % S == 0 ? cdiv(C, 4) : cdiv(C, 256))), dim3(256), 0, s, nbw, dsum, N, C, S, count, Wd, gamma, save,
                        save_se, dpool, nsum, cb, dgamma, dbeta, dz2, dz1, save_z, save_pool, dw1, db1, dw2, db2);

@@ -37,6 +37,9 @@ enum X3DOpt {
     X3D_OPT_DW_TSPLIT_WGS_FWD,  // the same threshold for the forward channelwise kernel (14 x 14 planes: 16.9 -> 14.7 us)  512
     X3D_OPT_NO_PW8,           // round 4: non-persistent pw6 / pw7 instead of the producer / consumer kernels pw8 / pw9  0
     X3D_OPT_PW8_GRID,         // workgroups of the persistent producer / consumer kernels (0 = one per CU)           0
+    X3D_OPT_PW8_MAX_K,        // largest padded K the persistent FORWARD kernel pw8 takes (0 = never; it wins at K <= 128)   128
+    X3D_OPT_PW9_MAX_K,        // largest padded K the persistent DATA-GRADIENT kernel pw9 takes (0 = never: it does not pay)  0
+    X3D_OPT_NO_SE_BWD_MERGE,  // separate reduce_tiles + se_bwd_sample launches instead of the merged per-sample kernel  0
     X3D_OPT_COUNT
 };
 int x3d_opt(int id);

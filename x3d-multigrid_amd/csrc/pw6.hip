@@ -245,6 +245,12 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
 // once per launch, and 12 waves at 3 per SIMD leave 170 registers per lane for resident A fragments.
 // item = mb * VT8 + vt (voxel tile, M block): the M blocks of one voxel tile run on the same XCD (ids 8 | VT8 apart).
 // ---------------------------------------------------------------------------------------
+// Workgroup barrier of the item pipeline: orders the LDS buffers only.  __syncthreads() compiles to "s_waitcnt vmcnt(0)
+// lgkmcnt(0); s_barrier": every barrier would drain the producers' just-issued loads of the NEXT item and the consumers'
+// output stores of the previous one (measured: 3 us per item instead of 1.5).  Global memory needs no ordering here: a
+// workgroup never reads what it wrote.
+__device__ __forceinline__ void p8_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int P8_NT = 768;          // 8 consumer + 4 producer waves
 constexpr int P8_PROD0 = 512;       // first producer thread
 constexpr int P8_RP = 32;           // rows staged per pass by the 256 producer threads
@@ -324,11 +330,11 @@ __global__ __launch_bounds__(P8_NT, 1) void pw8_kernel(const P6Args A) {
         for (int i = 0; i < niter; i += 2) {
             if (i + 1 < niter) issue(i + 1, rxb, cfb, pvb);
             stage(i, rxa, cfa, pva);
-            __syncthreads();                                         // barrier i: buffer i & 1 is full
+            p8_barrier();                                         // barrier i: buffer i & 1 is full
             if (i + 1 < niter) {
                 if (i + 2 < niter) issue(i + 2, rxa, cfa, pva);
                 stage(i + 1, rxb, cfb, pvb);
-                __syncthreads();                                     // barrier i + 1
+                p8_barrier();                                     // barrier i + 1
             }
         }
         return;
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(P8_NT, 1) void pw8_kernel(const P6Args A) {
 #pragma unroll
                 for (int s = 0; s < RD; ++s) fetch_a(j, s, ah[j][s], am[j][s], al[j][s]);
         }
-        __syncthreads();                                             // barrier i: buffer i & 1 is full
+        p8_barrier();                                             // barrier i: buffer i & 1 is full
         const __bf16* Xh = lds6 + (size_t)(i & 1) * bufsz;
         const __bf16* Xm = Xh + (size_t)Kp * P6_LD;
         const __bf16* Xl = Xm + (size_t)Kp * P6_LD;
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
     }
     };
     fetch_epi();
-    __syncthreads();
+    p8_barrier();
 
     f32x4 acc[2];
     const int tr_off = (8 * q + (r >> 2)) * P6_LD + 4 * (r & 3);
@@ -690,6 +696,282 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Round 4: persistent producer / consumer form of pw7_kernel (three-term operands, fp32 storage), the skeleton of
+// pw8_kernel: producers stage dY = cb0 g + cb1 a + cb2 of item i + 1 (g and a requested one item ahead in two register
+// sets), consumers run the MFMA loop of item i with resident / ring A fragments of the TRANSPOSED pack and the epilogue
+// (activation backward / residual backward / addend, statistics, stores); the epilogue's operands are requested in front of
+// the barrier, so they land while the consumers wait for the buffer and run the K loop.  Same products in the same order
+// as pw7_kernel<.., NS = 3>: bitwise the same dX and statistics tiles.
+// ---------------------------------------------------------------------------------------
+template <int EPI, int KG, int TPW>
+__global__ __launch_bounds__(P8_NT, 1) void pw9_kernel(const P7Args A) {
+    constexpr int RD = P8Ring<KG, TPW>::RD;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = A.K, P = A.P, M = A.M;
+    const int kg32 = (K + 31) / 32, kg16 = (K + 15) / 16, Kp = kg32 * 32;
+    const size_t bufsz = (size_t)3 * Kp * P6_LD;
+    const int VT = A.N * A.tiles, VT8 = (VT + 7) & ~7;
+    const int items = VT8 * A.mblocks;
+    const int G = (int)gridDim.x;
+    const int niter = (items - (int)blockIdx.x + G - 1) / G;
+
+    if (wave >= 8) {
+        // ------------------------------------------------ producers
+        const int pt = tid - P8_PROD0;
+        const int c4 = (pt & 7) * 4, row0 = pt >> 3;
+        const int colE = c4 >> 1, colO = colE + 16;
+        float4 rga[KG], raa[KG], rgb[KG], rab[KG];
+        int na = 0, nb = 0;
+        bool pva = false, pvb = false;
+        auto issue = [&](int i, float4 (&rg)[KG], float4 (&ra)[KG], int& nn, bool& pvv) {
+            const int it = (int)blockIdx.x + i * G;
+            const int mb = it / VT8;
+            const int vt = min(it - mb * VT8, VT - 1);
+            const int n = vt / A.tiles, tile = vt - n * A.tiles;
+            const int pt0 = tile * P6_BN;
+            const int pc = min(pt0 + c4, P - 4);
+            pvv = pt0 + c4 < P;
+            nn = n;
+            const float* gs = reinterpret_cast<const float*>(A.g) + (size_t)n * K * (size_t)P;
+            const float* as = reinterpret_cast<const float*>(A.a) + (size_t)n * K * (size_t)P;
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                const unsigned k = (unsigned)min(row0 + P8_RP * j, K - 1);
+                const size_t off = (size_t)k * (unsigned)P + (unsigned)pc;
+                rg[j] = *reinterpret_cast<const float4*>(gs + off);
+                ra[j] = *reinterpret_cast<const float4*>(as + off);
+            }
+        };
+        auto stage = [&](int i, const float4 (&rg)[KG], const float4 (&ra)[KG], int n, bool pvv) {
+            __bf16* Dh = lds6 + (size_t)(i & 1) * bufsz;
+            __bf16* Dm = Dh + (size_t)Kp * P6_LD;
+            __bf16* Dl = Dm + (size_t)Kp * P6_LD;
+            const float* cs = A.cb + (size_t)n * K * 3;
+            float k0[KG], k1[KG], k2[KG];                            // (L2-resident, 12 B per row: requested at use)
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                const unsigned k = (unsigned)min(row0 + P8_RP * j, K - 1);
+                const float* c3 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(cs) + k * 12u);
+                k0[j] = c3[0]; k1[j] = c3[1]; k2[j] = c3[2];
+            }
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                const int row = row0 + P8_RP * j;
+                if (row < Kp) {
+                    const bool ok = pvv && row < K;
+                    const float gv[4] = {rg[j].x, rg[j].y, rg[j].z, rg[j].w}, av[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
+                    float xs[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xs[e] = ok ? fmaf(k0[j], gv[e], fmaf(k1[j], av[e], k2[j])) : 0.f;
+                    unsigned hE, mE, lE, hO, mO, lO;
+                    x3d_split3_pair(xs[0], xs[2], hE, mE, lE);
+                    x3d_split3_pair(xs[1], xs[3], hO, mO, lO);
+                    *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colE]) = __builtin_bit_cast(bf16x2, hE);
+                    *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colO]) = __builtin_bit_cast(bf16x2, hO);
+                    *reinterpret_cast<bf16x2*>(&Dm[row * P6_LD + colE]) = __builtin_bit_cast(bf16x2, mE);
+                    *reinterpret_cast<bf16x2*>(&Dm[row * P6_LD + colO]) = __builtin_bit_cast(bf16x2, mO);
+                    *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colE]) = __builtin_bit_cast(bf16x2, lE);
+                    *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colO]) = __builtin_bit_cast(bf16x2, lO);
+                }
+            }
+        };
+        issue(0, rga, raa, na, pva);
+        if (KG <= 4) {
+            for (int i = 0; i < niter; i += 2) {
+                if (i + 1 < niter) issue(i + 1, rgb, rab, nb, pvb);
+                stage(i, rga, raa, na, pva);
+                p8_barrier();
+                if (i + 1 < niter) {
+                    if (i + 2 < niter) issue(i + 2, rga, raa, na, pva);
+                    stage(i + 1, rgb, rab, nb, pvb);
+                    p8_barrier();
+                }
+            }
+        } else {
+            // K > 128: two register sets of g and a (16 KG registers) do not fit beside the coefficients -- ONE set, the
+            // next item requested right behind the staging: its latency overlaps the barrier wait (the consumers' MFMA
+            // loop is the longer phase at these K)
+            for (int i = 0; i < niter; ++i) {
+                stage(i, rga, raa, na, pva);
+                if (i + 1 < niter) issue(i + 1, rga, raa, na, pva);
+                p8_barrier();
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- consumers
+    const int q = lane >> 4, r = lane & 15;
+    const int mtiles = (M + 15) / 16;
+    const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
+    const size_t plane = (size_t)mtiles * kg32 * 512;
+    const int tr_off = (8 * q + (r >> 2)) * P6_LD + 4 * (r & 3);
+    const bool resident = (RD == KG) && A.mblocks == 1;
+    bf16x8 ah[TPW][RD], am[TPW][RD], al[TPW][RD];
+    const __bf16* wa[TPW];
+    bool tok[TPW];
+    int mt[TPW];
+    auto set_tiles = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int t = wave + 8 * j;
+            tok[j] = t < A.mt_run && mb * A.mt_run + t < mtiles;
+            mt[j] = min(mb * A.mt_run + t, mtiles - 1);
+            wa[j] = wq + ((size_t)mt[j] * kg32 * 64 + lane) * 8;
+        }
+    };
+    auto fetch_a = [&](int j, int s, bf16x8& h, bf16x8& m, bf16x8& l) {
+        const int sc = min(s, kg32 - 1);
+        h = *reinterpret_cast<const bf16x8*>(wa[j] + (size_t)sc * 512);
+        m = *reinterpret_cast<const bf16x8*>(wa[j] + (size_t)sc * 512 + plane);
+        l = *reinterpret_cast<const bf16x8*>(wa[j] + (size_t)sc * 512 + 2 * plane);
+    };
+    auto tr_frag = [&](const __bf16* pln, int s, int h2) -> bf16x8 {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const __bf16* p0 = pln + 32 * s * P6_LD + tr_off + 16 * h2;
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * P6_LD));
+        return cat8_(v0, v1);
+    };
+    const bool has_add = A.addend != nullptr;
+    const bool add_s2 = has_add && A.addend_stride == 2;
+    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+    int cur_mb = -1;
+    for (int i = 0; i < niter; ++i) {
+        const int it = (int)blockIdx.x + i * G;
+        const int mb = it / VT8;
+        const int vt0 = it - mb * VT8;
+        const bool valid = vt0 < VT;
+        const int vt = min(vt0, VT - 1);
+        const int n = vt / A.tiles, tile = vt - n * A.tiles;
+        const int pt0 = tile * P6_BN;
+        if (!resident || i == 0) {
+            if (mb != cur_mb) { set_tiles(mb); cur_mb = mb; }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+#pragma unroll
+                for (int s = 0; s < RD; ++s) fetch_a(j, s, ah[j][s], am[j][s], al[j][s]);
+        }
+        // ---- epilogue operands of this item (lane (q, r): rows 4 q + e of a tile, voxels 2 r, 2 r + 1), requested now
+        const int pl = pt0 + 2 * r;
+        const bool pv = valid && pl < P;              // P even: both voxels or none
+        const int pc2 = pv ? pl : 0;
+        int aoff[2] = {pc2, pc2 + 1};
+        bool av[2] = {has_add && pv, has_add && pv};
+        if (add_s2) {
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int p = pc2 + j2;
+                const int hw = A.H * A.W;
+                const int t = p / hw, rem = p - t * hw;
+                const int h = rem / A.W, w = rem - h * A.W;
+                const bool even = !(h & 1) && !(w & 1);
+                av[j2] = av[j2] && even;
+                aoff[j2] = even ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0;
+            }
+        }
+        float xv[TPW][4][2], mk[TPW][4][2], adv[TPW][4][2], esc[TPW][4], esh[TPW][4];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = mt[j] * 16 + 4 * q + e;
+                const size_t mrow = (size_t)n * M + (m < M ? m : 0);
+                if (EPI == P7_ACTBWD) {
+                    const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
+                    esc[j][e] = c2.x; esh[j][e] = c2.y;
+                }
+                if (EPI != P7_PLAIN) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(A.ex) + mrow * (size_t)P + pc2);
+                    xv[j][e][0] = t2.x; xv[j][e][1] = t2.y;
+                }
+                if (EPI == P7_RESBWD) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(A.emask + mrow * (size_t)P + pc2);
+                    mk[j][e][0] = t2.x; mk[j][e][1] = t2.y;
+                }
+                if (has_add) {
+                    const float* pa = A.addend + mrow * (size_t)addP;
+                    if (!add_s2) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(pa + pc2);
+                        adv[j][e][0] = t2.x; adv[j][e][1] = t2.y;
+                    } else {
+                        adv[j][e][0] = pa[aoff[0]]; adv[j][e][1] = pa[aoff[1]];
+                    }
+                }
+            }
+        }
+        p8_barrier();                                             // barrier i: buffer i & 1 is full
+        const __bf16* Dh = lds6 + (size_t)(i & 1) * bufsz;
+        const __bf16* Dm = Dh + (size_t)Kp * P6_LD;
+        const __bf16* Dl = Dm + (size_t)Kp * P6_LD;
+        f32x4 acc[TPW][2];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (tok[0]) {
+#pragma unroll
+            for (int s = 0; s < KG; ++s) {
+                if (s < kg32) {
+                    const int slot = s % RD;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const bf16x8 bh = tr_frag(Dh, s, h2), bm = tr_frag(Dm, s, h2), bl = tr_frag(Dl, s, h2);
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j) {
+                            if (j == 0 || tok[j]) {                  // smallest terms first, as pw7_kernel<.., 3>
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j][slot], bh, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bl, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j][slot], bm, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j][slot], bh, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bm, acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bh, acc[j][h2], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (RD < KG && s + RD < kg32) {
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j) fetch_a(j, s + RD, ah[j][slot], am[j][slot], al[j][slot]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (j == 0 || tok[j]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = mt[j] * 16 + 4 * q + e;
+                        const bool mv = m < M;
+                        float v[2] = {acc[j][0][e], acc[j][1][e]};
+                        float s1 = 0.f, s2 = 0.f;
+                        if (has_add) { v[0] += av[0] ? adv[j][e][0] : 0.f; v[1] += av[1] ? adv[j][e][1] : 0.f; }
+                        if (EPI != P7_PLAIN) {
+#pragma unroll
+                            for (int j2 = 0; j2 < 2; ++j2) {
+                                const float xj = pv ? xv[j][e][j2] : 0.f;
+                                if (EPI == P7_RESBWD) v[j2] = (pv && mk[j][e][j2] > 0.f) ? v[j2] : 0.f;
+                                else v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[j][e], xj, esh[j][e]), A.e_act) : 0.f;
+                                s1 += v[j2];
+                                s2 = fmaf(v[j2], xj, s2);
+                            }
+                        }
+                        if (mv && pv) *reinterpret_cast<float2*>(reinterpret_cast<float*>(A.y) + ((size_t)n * M + m) * (size_t)P + pl) = make_float2(v[0], v[1]);
+                        if (EPI != P7_PLAIN && A.partial != nullptr) {
+                            s1 = row16_sum(s1);
+                            s2 = row16_sum(s2);
+                            if (r == 0 && mv && valid) {
+                                float* pp = A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2;
+                                pp[0] = s1; pp[1] = s2;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // shapes pw6 takes (the caller has checked: dense, packed weights present)
@@ -732,7 +1014,7 @@ int x3d_pw6_launch(const void* x, const float* cin, const float* wp, void* y, fl
         if (npass <= 2) P6_GO(AFF, 2, MX_); else if (npass <= 4) P6_GO(AFF, 4, MX_); else P6_GO(AFF, 7, MX_);  \
     } while (0)
     // round 4: the persistent producer / consumer form (fp32 storage, K <= 224: two LDS buffers of three planes each)
-    if (!x_bf && !y_bf && kp <= 224 && !x3d_opt(X3D_OPT_NO_PW8)) {
+    if (!x_bf && !y_bf && kp <= x3d_opt(X3D_OPT_PW8_MAX_K) && !x3d_opt(X3D_OPT_NO_PW8)) {
         const int tpw = mtiles <= 8 ? 1 : 2;
         A.mblocks = cdiv(mtiles, 8 * tpw);
         A.mt_run = cdiv(mtiles, A.mblocks);
@@ -805,6 +1087,42 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
     const int ns = x3d_opt(X3D_OPT_BWD_TERMS) == 2 ? 2 : 3;
     const size_t lds = (size_t)ns * kp * P6_LD * sizeof(__bf16);
     const int npass = cdiv(kp, P6_RP);
+    // round 4: the persistent producer / consumer form (three-term operands, fp32 storage, K <= 224)
+    if (!ga_bf && !y_bf && !ex_bf && ns == 3 && kp <= x3d_opt(X3D_OPT_PW9_MAX_K) && !x3d_opt(X3D_OPT_NO_PW8)) {
+        const int tpw = mtiles <= 8 ? 1 : 2;
+        A.mblocks = cdiv(mtiles, 8 * tpw);
+        A.mt_run = cdiv(mtiles, A.mblocks);
+        const int vt8 = (VT + 7) & ~7;
+        const int items = vt8 * A.mblocks;
+        int g = x3d_opt(X3D_OPT_PW8_GRID);
+        if (g <= 0) g = x3d_cu_count();
+        if (g > items) g = items;
+        const size_t lds9 = (size_t)2 * 3 * kp * P6_LD * sizeof(__bf16);
+        const int kg = kp / 32;
+#define P9_GO(EPI_, KG_, TPW_)                                                                                      \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw9_kernel<EPI_, KG_, TPW_>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 32 * KG_ * P6_LD * 2);     \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((pw9_kernel<EPI_, KG_, TPW_>), dim3(g), dim3(P8_NT), lds9, s, A);                         \
+    } while (0)
+#define P9_KG(EPI_, TPW_)                                                                                           \
+    do {                                                                                                            \
+        if (kg <= 3) P9_GO(EPI_, 3, TPW_); else if (kg <= 4) P9_GO(EPI_, 4, TPW_);                                   \
+        else if (kg <= 6) P9_GO(EPI_, 6, TPW_); else P9_GO(EPI_, 7, TPW_);                                           \
+    } while (0)
+#define P9_EPI(EPI_) do { if (tpw == 1) P9_KG(EPI_, 1); else P9_KG(EPI_, 2); } while (0)
+        x3d_note_kernel("pw9_kernel");
+        if (mode == P7_PLAIN) P9_EPI(P7_PLAIN); else if (mode == P7_ACTBWD) P9_EPI(P7_ACTBWD); else P9_EPI(P7_RESBWD);
+#undef P9_EPI
+#undef P9_KG
+#undef P9_GO
+        X3D_LAUNCH_CHECK();
+        return X3D_OK;
+    }
 #define P7_GO2(EPI_, NP, MX_, NS_)                                                                                  \
     do {                                                                                                            \
         static bool attr_done = false;                                                                              \
