@@ -216,6 +216,50 @@ def test_pw_bwd_persistent_kernel_is_bitwise_the_whole_k_kernel(case, grid):
             assert torch.equal(u, v), i
 
 
+@pytest.mark.parametrize("case", [(8, 432, 192, 16, 7, 7), (2, 432, 192, 4, 5, 5), (2, 432, 200, 3, 6, 6), (3, 352, 150, 2, 5, 8),
+                                  (2, 448, 256, 2, 4, 4)])
+def test_pw_sixteen_wave_workgroups_are_bitwise_the_eight_wave_kernels(case):
+    """pw6 / pw7 with 16-wave workgroups on the K >= 320 layers (round 4, option pw_waves16) against the 8-wave form (two M
+    tiles per wave): forward (BN * SE + Swish prologue) and the data gradient of the transposed layer in all epilogue modes,
+    y / dX and the statistics tiles BITWISE equal."""
+    from x3dhip import _lib, ops
+    dev = _dev()
+    N, K, M, T, H, W = case
+    x = _g(N, K, T, H, W, seed=1).float().to(dev)
+    w = (_g(M, K, seed=2) / np.sqrt(K)).float().to(dev)              # forward: K -> M
+    pre = torch.stack([1 + 0.2 * _g(N, K, seed=3), 0.3 * _g(N, K, seed=4)], -1).float().contiguous().to(dev)
+    wp = ops.pw_pack(w)
+    # data gradient of a conv M -> K (GEMM K = its Cout = K here, M rows = its Cin = M)
+    wb = (_g(K, M, seed=5) / np.sqrt(K)).float().to(dev)
+    wpt = ops.pw_pack(wb, transposed=True)
+    g = _g(N, K, T, H, W, seed=6).float().to(dev)
+    a = _g(N, K, T, H, W, seed=7).float().to(dev)
+    cb = torch.stack([1 + 0.2 * _g(N, K, seed=8), 0.1 * _g(N, K, seed=9), 0.05 * _g(N, K, seed=10)], -1).float().contiguous().to(dev)
+    xin = _g(N, M, T, H, W, seed=11).float().to(dev)
+    prei = torch.stack([1 + 0.2 * _g(N, M, seed=12), 0.3 * _g(N, M, seed=13)], -1).float().contiguous().to(dev)
+    res_out = torch.relu(_g(N, M, T, H, W, seed=14)).float().to(dev)
+    res_raw = _g(N, M, T, H, W, seed=15).float().to(dev)
+    add1 = _g(N, M, T, H, W, seed=16).float().to(dev)
+
+    def run():
+        outs = list(ops.pw_fwd(x, w, pre=pre, pre_act=2, wp=wp))
+        outs.append(_lib.last_kernel())
+        outs += list(ops.pw_fwd(x, w, wp=wp))
+        outs.append(ops.pw_bwd_data(g, a, cb, wb, wpt=wpt)[0])
+        outs += list(ops.pw_bwd_data(g, a, cb, wb, x=xin, pre=prei, pre_act=2, wpt=wpt))
+        outs += list(ops.pw_bwd_data_res(g, a, cb, wb, res_out, res_raw, addend=add1, wpt=wpt))
+        torch.cuda.synchronize()
+        return outs
+
+    with _lib.options(pw_waves16=0):
+        r0 = run()
+    r1 = run()
+    assert r0[2] == "pw6_kernel" and r1[2] == "pw6_kernel"
+    for i, (u, v) in enumerate(zip(r0, r1)):
+        if i != 2:
+            assert torch.equal(u, v), i
+
+
 def _terms(terms):
     """Backward GEMM operand split for the duration of a test: 3 bf16 terms (default, fp32 level) or 2 (~2^-16)."""
     from x3dhip import _lib

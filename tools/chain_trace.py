@@ -21,7 +21,7 @@ def short(name):
     return name.split("(")[0][:60]
 
 
-FINALIZE = ("bn_fwd_fused", "bn_bwd_fused", "se_fwd", "se_bwd", "se_tail", "reduce_tiles", "reduce_partials", "bn_eval")
+FINALIZE = ("bn_fwd_fused", "bn_bwd_fused", "se_fwd", "se_bn_fwd", "se_bwd", "se_tail", "reduce_tiles", "reduce_partials", "bn_eval")
 
 
 def klass(n):

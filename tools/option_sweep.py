@@ -45,10 +45,18 @@ def timed():
 
 base = timed()
 print("%-44s %7.3f ms/step  %7.1f clips/s" % ("defaults", base, 8e3 / base), flush=True)
+from x3dhip import engine  # noqa: E402
 for spec in args:
-    opts = {k: int(v) for k, v in (kv.split("=") for kv in spec.split(","))}
+    kv = dict(kv.split("=") for kv in spec.split(","))
+    opts = {k: int(v) for k, v in kv.items() if not k.startswith("cfg.")}
+    cfgs = {k[4:]: bool(int(v)) for k, v in kv.items() if k.startswith("cfg.")}       # schedule switches: cfg.wgrad_overlap=1
+    old = {k: getattr(engine.cfg, k) for k in cfgs}
+    for k, v in cfgs.items():
+        setattr(engine.cfg, k, v)
     with _lib.options(**opts):
         t = timed()
+    for k, v in old.items():
+        setattr(engine.cfg, k, v)
     print("%-44s %7.3f ms/step  %7.1f clips/s  (%+.2f %%)" % (spec, t, 8e3 / t, 100 * (base / t - 1)), flush=True)
 t = timed()
 print("%-44s %7.3f ms/step  %7.1f clips/s  (%+.2f %%)" % ("defaults again", t, 8e3 / t, 100 * (base / t - 1)), flush=True)

@@ -61,6 +61,7 @@ const OptDef kOpts[X3D_OPT_COUNT] = {
     /* X3D_OPT_PW8_MAX_K      */ {"pw8_max_k", "X3D_PW8_MAX_K", 128, 0},
     /* X3D_OPT_PW9_MAX_K      */ {"pw9_max_k", "X3D_PW9_MAX_K", 0, 0},
     /* X3D_OPT_NO_SE_BWD_MERGE */ {"no_se_bwd_merge", "X3D_NO_SE_BWD_MERGE", 0, 1},
+    /* X3D_OPT_PW_WAVES16     */ {"pw_waves16", "X3D_PW_WAVES16", 1, 0},
 };
 std::atomic<int> g_opt[X3D_OPT_COUNT];
 std::once_flag g_opt_once;

@@ -145,6 +145,11 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const float* __restri
     __shared__ double rows[2 * BN_MAXN];
     __shared__ float csc[BN_MAXS], csh[BN_MAXS];
     const int c = blockIdx.x, tid = threadIdx.x;
+    // (round 4) everything that does not depend on the statistics is requested in front of them: these finalize launches are
+    // chains of exposed memory round trips (~1 us each, the producer's data sits in another XCD's L2 / HBM), not arithmetic
+    const float gm = gamma[c], bt = beta[c];
+    const int j0 = tid < S ? tid : 0;
+    const float rm0 = rmean != nullptr ? rmean[(size_t)j0 * C + c] : 0.f, rv0 = rvar != nullptr ? rvar[(size_t)j0 * C + c] : 0.f;
     channel_row_sums(partial, N, C, c, tiles, rows);
     const double cnt = (double)count * (double)(N / S);
     for (int j = tid; j < S; j += 256) {
@@ -158,11 +163,12 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const float* __restri
         save[(size_t)(S + j) * C + c] = (float)invstd;
         if (rmean != nullptr) {
             const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-            rmean[(size_t)j * C + c] = (float)((1.0 - momentum) * rmean[(size_t)j * C + c] + momentum * mean);
-            rvar[(size_t)j * C + c] = (float)((1.0 - momentum) * rvar[(size_t)j * C + c] + momentum * unb);
+            const float rmj = j == j0 ? rm0 : rmean[(size_t)j * C + c], rvj = j == j0 ? rv0 : rvar[(size_t)j * C + c];
+            rmean[(size_t)j * C + c] = (float)((1.0 - momentum) * rmj + momentum * mean);
+            rvar[(size_t)j * C + c] = (float)((1.0 - momentum) * rvj + momentum * unb);
         }
-        csc[j] = (float)((double)gamma[c] * invstd);
-        csh[j] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+        csc[j] = (float)((double)gm * invstd);
+        csh[j] = (float)((double)bt - mean * (double)gm * invstd);
     }
     __syncthreads();
     for (int n = tid; n < N; n += 256) {
@@ -181,13 +187,15 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
     __shared__ float cA[BN_MAXS], cB[BN_MAXS], cC[BN_MAXS];
     __shared__ double dgs[BN_MAXS], dbs[BN_MAXS];
     const int c = blockIdx.x, tid = threadIdx.x;
+    const double g = gamma[c];                           // (requested in front of the statistics: see bn_fwd_fused_kernel)
+    const int j0 = tid < S ? tid : 0;
+    const float mean0 = save[(size_t)j0 * C + c], invstd0 = save[(size_t)(S + j0) * C + c];
     channel_row_sums(partial, N, C, c, tiles, rows);
     const double M = (double)count * (double)(N / S);
-    const double g = gamma[c];
     for (int j = tid; j < S; j += 256) {
         double sg = 0.0, sga = 0.0;
         for (int n = j; n < N; n += S) { sg += rows[2 * n]; sga += rows[2 * n + 1]; }
-        const double mean = save[(size_t)j * C + c], invstd = save[(size_t)(S + j) * C + c];
+        const double mean = j == j0 ? mean0 : save[(size_t)j * C + c], invstd = j == j0 ? invstd0 : save[(size_t)(S + j) * C + c];
         const double sgx = (sga - mean * sg) * invstd;
         const double k = g * invstd;
         cA[j] = (float)k;

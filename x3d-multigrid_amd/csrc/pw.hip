@@ -2467,6 +2467,16 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     double s = 0.0;
     if (i < n) {
         int g = wave;
+        for (; g + 60 < groups; g += 64) {           // round 4: sixteen rows in flight per wave (512 groups: 8 round trips)
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(g + 4 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 16; u += 8) {          // same grouping of the additions as the eight-row loop below
+                s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
+                s += ((double)v[u + 4] + (double)v[u + 5]) + ((double)v[u + 6] + (double)v[u + 7]);
+            }
+        }
         for (; g + 28 < groups; g += 32) {           // eight rows in flight per wave (512 groups: 16 round trips instead of 32)
             const float v0 = partial[(size_t)g * n + i], v1 = partial[(size_t)(g + 4) * n + i];
             const float v2 = partial[(size_t)(g + 8) * n + i], v3 = partial[(size_t)(g + 12) * n + i];
@@ -2512,6 +2522,16 @@ __global__ __launch_bounds__(256) void reduce_partials_batch_kernel(const Reduce
     double s = 0.0;
     if (i < n) {
         int g = wave;
+        for (; g + 60 < groups; g += 64) {           // round 4: sixteen rows in flight per wave (512 groups: 8 round trips)
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(g + 4 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 16; u += 8) {          // same grouping of the additions as the eight-row loop below
+                s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
+                s += ((double)v[u + 4] + (double)v[u + 5]) + ((double)v[u + 6] + (double)v[u + 7]);
+            }
+        }
         for (; g + 28 < groups; g += 32) {           // eight rows in flight per wave (512 groups: 16 round trips instead of 32)
             const float v0 = partial[(size_t)g * n + i], v1 = partial[(size_t)(g + 4) * n + i];
             const float v2 = partial[(size_t)(g + 8) * n + i], v3 = partial[(size_t)(g + 12) * n + i];

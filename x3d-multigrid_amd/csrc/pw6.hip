@@ -52,8 +52,12 @@ extern "C" int x3d_debug_p6trace(void* dst, size_t bytes) { return (int)hipMemcp
 #define P6T(i) do { } while (0)
 #endif
 
-template <int IN_AFF, int NPASS, bool MX>
-__global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
+// NW: waves per workgroup -- 8, or 16 (round 4) for the K >= 320 layers of stage 4, whose three LDS planes leave room for ONE
+// workgroup per CU anyway: twice the threads stage the tile (4 instead of 7 rows per thread) and every M tile of the layer
+// has its own wave (12 tiles on 16 waves instead of two tiles on each of 4 of 8 waves) -- the phases of the single
+// resident workgroup (staging -> barrier -> MFMA -> stores) each take half as long.
+template <int IN_AFF, int NPASS, bool MX, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 4) void pw6_kernel(const P6Args A) {
 #ifdef X3D_TRACE
     unsigned long long p6t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
 
     // ---- stage: whole K x 32 voxels in one burst
     const int c4 = (tid & 7) * 4, row0 = tid >> 3;
+    constexpr int RP = 8 * NW;                 // rows staged per pass
     const int pc = min(pt + c4, P - 4);
     const bool pvv = pt + c4 < P;
     const int colE = c4 >> 1, colO = colE + 16;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
     float2 cf[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-        const unsigned k = (unsigned)min(row0 + P6_RP * i, K - 1);
+        const unsigned k = (unsigned)min(row0 + RP * i, K - 1);
         rx[i] = ldo4_raw(xs, k * (unsigned)P + (unsigned)pc, x_bf);      // widened at the staging below
         if (IN_AFF) cf[i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cs) + k * 8u);
     }
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
 
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-        const int row = row0 + P6_RP * i;
+        const int row = row0 + RP * i;
         if (row < Kp) {
             const bool ok = pvv && row < K;
             const float4 xw = widen4(rx[i], x_bf);
@@ -174,10 +179,10 @@ __global__ __launch_bounds__(P6_NT, 4) void pw6_kernel(const P6Args A) {
     };
     for (int pass = 0; pass < 2; ++pass) {
       if (pass == 1) {                            // second tile of this wave (blocks of more than 8 tiles): w + 8
-        if (A.mt_run <= 8) break;
-        mt_ok = wave + 8 < A.mt_run && mb * A.mt_run + wave + 8 < mtiles;
+        if (A.mt_run <= NW) break;
+        mt_ok = wave + NW < A.mt_run && mb * A.mt_run + wave + NW < mtiles;
         if (!mt_ok) break;
-        mt = mb * A.mt_run + wave + 8;
+        mt = mb * A.mt_run + wave + NW;
         wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) fetch_a(i, ah[i], am[i], al[i]);
@@ -477,8 +482,8 @@ struct P7Args {
 // NS: bf16 terms per fp32 operand -- 3 (hi + mid + lo = all 24 significant bits, six MFMA products: fp32-level, as pw6; the
 // default) or 2 (hi + lo, three products, ~2^-16 per product; option bwd_terms = 2).  The transposed pack always carries
 // three planes; the two-term form reads hi and mid (mid = bf16(v - hi) is exactly its "lo").
-template <int EPI, int NPASS, bool MX, int NS>
-__global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const P7Args A) {
+template <int EPI, int NPASS, bool MX, int NS, int NW = 8>      // NW: waves per workgroup, see pw6_kernel
+__global__ __launch_bounds__(64 * NW, (NW == 16 || NPASS <= 4) ? 4 : 2) void pw7_kernel(const P7Args A) {
     const int ga_bf = MX ? A.ga_bf : 0, y_bf = MX ? A.y_bf : 0, ex_bf = MX ? A.ex_bf : 0;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -501,6 +506,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
     // ---- stage dY: whole K x 32 voxels of g and a in one burst
     {
         const int c4 = (tid & 7) * 4, row0 = tid >> 3;
+        constexpr int RP = 8 * NW;
         const int pc = min(pt + c4, P - 4);
         const bool pvv = pt + c4 < P;
         const int colE = c4 >> 1, colO = colE + 16;
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
         float k0[NPASS], k1[NPASS], k2[NPASS];
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const unsigned k = (unsigned)min(row0 + P6_RP * i, K - 1);
+            const unsigned k = (unsigned)min(row0 + RP * i, K - 1);
             const unsigned off = k * (unsigned)P + (unsigned)pc;
             rg[i] = ldo4_raw(gs, off, ga_bf);
             ra[i] = ldo4_raw(as, off, ga_bf);
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
         }
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const int row = row0 + P6_RP * i;
+            const int row = row0 + RP * i;
             if (row < Kp) {
                 const bool ok = pvv && row < K;
                 const float4 gw = widen4(rg[i], ga_bf), aw = widen4(ra[i], ga_bf);
@@ -642,10 +648,10 @@ __global__ __launch_bounds__(P6_NT, (NPASS <= 4) ? 4 : 2) void pw7_kernel(const 
     };
     for (int pass = 0; pass < 2; ++pass) {
       if (pass == 1) {                            // second tile of this wave (blocks of more than 8 tiles): w + 8
-        if (A.mt_run <= 8) break;
-        mt_ok = wave + 8 < A.mt_run && mb * A.mt_run + wave + 8 < mtiles;
+        if (A.mt_run <= NW) break;
+        mt_ok = wave + NW < A.mt_run && mb * A.mt_run + wave + NW < mtiles;
         if (!mt_ok) break;
-        mt = mb * A.mt_run + wave + 8;
+        mt = mb * A.mt_run + wave + NW;
         wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) fetch_a(i, ah[i], am[i], al[i]);
@@ -1048,6 +1054,24 @@ int x3d_pw6_launch(const void* x, const float* cin, const float* wp, void* y, fl
         X3D_LAUNCH_CHECK();
         return X3D_OK;
     }
+    // round 4: 16-wave workgroups for the K >= 320 layers (one workgroup per CU either way; fp32 storage)
+    if (!x_bf && !y_bf && per == 16 && A.mt_run <= 16 && kp <= 512 && x3d_opt(X3D_OPT_PW_WAVES16)) {
+#define P6_GO16(AFF)                                                                                                \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw6_kernel<AFF, 4, false, 16>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 512 * P6_LD * 2);              \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((pw6_kernel<AFF, 4, false, 16>), grid, dim3(1024), lds, s, A);                            \
+    } while (0)
+        x3d_note_kernel("pw6_kernel");
+        if (cin) P6_GO16(1); else P6_GO16(0);
+#undef P6_GO16
+        X3D_LAUNCH_CHECK();
+        return X3D_OK;
+    }
     x3d_note_kernel("pw6_kernel");
     if (x_bf || y_bf) { if (cin) P6_PASS(1, true); else P6_PASS(0, true); }
     else if (cin) P6_PASS(1, false); else P6_PASS(0, false);
@@ -1138,6 +1162,23 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
     do {                                                                                                             \
         if (npass <= 2) P7_GO(EPI_, 2, MX_); else if (npass <= 4) P7_GO(EPI_, 4, MX_); else P7_GO(EPI_, 7, MX_);     \
     } while (0)
+    if (!ga_bf && !y_bf && !ex_bf && ns == 3 && per == 16 && A.mt_run <= 16 && kp <= 512 && x3d_opt(X3D_OPT_PW_WAVES16)) {
+#define P7_GO16(EPI_)                                                                                               \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, 4, false, 3, 16>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 512 * P6_LD * 2);              \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((pw7_kernel<EPI_, 4, false, 3, 16>), grid, dim3(1024), lds, s, A);                        \
+    } while (0)
+        x3d_note_kernel("pw7_kernel");
+        if (mode == P7_PLAIN) P7_GO16(P7_PLAIN); else if (mode == P7_ACTBWD) P7_GO16(P7_ACTBWD); else P7_GO16(P7_RESBWD);
+#undef P7_GO16
+        X3D_LAUNCH_CHECK();
+        return X3D_OK;
+    }
     x3d_note_kernel("pw7_kernel");
     if (ga_bf || y_bf || ex_bf) {
         if (mode == P7_PLAIN) P7_PASS(P7_PLAIN, true); else if (mode == P7_ACTBWD) P7_PASS(P7_ACTBWD, true); else P7_PASS(P7_RESBWD, true);
