@@ -217,7 +217,9 @@ def test_pw_bwd_persistent_kernel_is_bitwise_the_whole_k_kernel(case, grid):
 
 
 @pytest.mark.parametrize("case", [(8, 432, 192, 16, 7, 7), (2, 432, 192, 4, 5, 5), (2, 432, 200, 3, 6, 6), (3, 352, 150, 2, 5, 8),
-                                  (2, 448, 256, 2, 4, 4)])
+                                  (2, 448, 256, 2, 4, 4),
+                                  # mode 2: more than 8 M tiles at any K (27 tiles = two per wave, 14 tiles, 32 tiles)
+                                  (2, 192, 432, 4, 5, 5), (2, 96, 216, 4, 10, 10), (2, 128, 512, 2, 4, 4), (2, 216, 300, 3, 6, 6)])
 def test_pw_sixteen_wave_workgroups_are_bitwise_the_eight_wave_kernels(case):
     """pw6 / pw7 with 16-wave workgroups on the K >= 320 layers (round 4, option pw_waves16) against the 8-wave form (two M
     tiles per wave): forward (BN * SE + Swish prologue) and the data gradient of the transposed layer in all epilogue modes,
@@ -251,13 +253,15 @@ def test_pw_sixteen_wave_workgroups_are_bitwise_the_eight_wave_kernels(case):
         torch.cuda.synchronize()
         return outs
 
-    with _lib.options(pw_waves16=0):
+    with _lib.options(pw_waves16=0, no_pw8=1):
         r0 = run()
-    r1 = run()
-    assert r0[2] == "pw6_kernel" and r1[2] == "pw6_kernel"
-    for i, (u, v) in enumerate(zip(r0, r1)):
-        if i != 2:
-            assert torch.equal(u, v), i
+    for mode in (1, 2, 3):
+        with _lib.options(pw_waves16=mode, no_pw8=1):
+            r1 = run()
+        assert r0[2] == "pw6_kernel" and r1[2] == "pw6_kernel"
+        for i, (u, v) in enumerate(zip(r0, r1)):
+            if i != 2:
+                assert torch.equal(u, v), (mode, i)
 
 
 def _terms(terms):

@@ -43,7 +43,7 @@ for name, N, Ci, Co, T, H, act in LAYERS:
     y = torch.empty(N, Co, T, H, H, device=dev)
     part = torch.empty(N, Co, _lib.lib().x3d_pw_fwd_tiles(N, Ci, Co, T * H * H, 1, 1), 2, device=dev)
     res = {}
-    for tag, opts in (("pw6 8w", dict(no_pw8=1, pw_waves16=0)), ("pw6", dict(no_pw8=1)), ("pw8", dict(pw8_max_k=224)), ("pw8 g512", dict(pw8_grid=512, pw8_max_k=224)), ("pw8 g128", dict(pw8_grid=128, pw8_max_k=224))):
+    for tag, opts in (("pw6 8w", dict(no_pw8=1, pw_waves16=0)), ("pw6", dict(no_pw8=1)), ("pw6 w16=3", dict(no_pw8=1, pw_waves16=3)), ("pw8", dict(pw8_max_k=224)), ("pw8 g512", dict(pw8_grid=512, pw8_max_k=224)), ("pw8 g128", dict(pw8_grid=128, pw8_max_k=224))):
         with _lib.options(**opts):
             res[tag] = (t(lambda: ops.pw_fwd(x, w, pre=pre, pre_act=act, out=y, partial=part, wp=wp)), _lib.last_kernel())
     print("%-26s fwd  " % name + "  ".join("%s %.2f us (%s)" % (k, v[0], v[1]) for k, v in res.items()), flush=True)
@@ -52,7 +52,7 @@ for name, N, Ci, Co, T, H, act in LAYERS:
     xo_ = torch.relu(torch.randn(N, Ci, T, H, H, device=dev)); ex = torch.randn(N, Ci, T, H, H, device=dev)
     pre2 = torch.rand(N, Ci, 2, device=dev) + 0.5
     res = {}
-    for tag, opts in (("pw7 8w", dict(no_pw8=1, pw_waves16=0)), ("pw7", dict(no_pw8=1)), ("pw9", dict(pw9_max_k=224))):
+    for tag, opts in (("pw7 8w", dict(no_pw8=1, pw_waves16=0)), ("pw7", dict(no_pw8=1)), ("pw7 w16=3", dict(no_pw8=1, pw_waves16=3)), ("pw9", dict(pw9_max_k=224))):
         with _lib.options(**opts):
             ta = t(lambda: ops.pw_bwd_data(g, a, cb, w, x=ex, pre=pre2, pre_act=2, wpt=wpt))
             ka = _lib.last_kernel()

@@ -40,7 +40,7 @@ enum X3DOpt {
     X3D_OPT_PW8_MAX_K,        // largest padded K the persistent FORWARD kernel pw8 takes (0 = never; it wins at K <= 128)   128
     X3D_OPT_PW9_MAX_K,        // largest padded K the persistent DATA-GRADIENT kernel pw9 takes (0 = never: it does not pay)  0
     X3D_OPT_NO_SE_BWD_MERGE,  // separate reduce_tiles + se_bwd_sample launches instead of the merged per-sample kernel  0
-    X3D_OPT_PW_WAVES16,       // whole-K kernels pw6 / pw7: 16-wave workgroups for the K >= 320 layers (round 4)          1
+    X3D_OPT_PW_WAVES16,       // whole-K kernels pw6 / pw7, 16-wave workgroups: 0 never, 1 K >= 320, 2 also > 16 M tiles, 3 also > 8   2
     X3D_OPT_COUNT
 };
 int x3d_opt(int id);

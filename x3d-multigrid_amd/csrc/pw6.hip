@@ -1054,20 +1054,30 @@ int x3d_pw6_launch(const void* x, const float* cin, const float* wp, void* y, fl
         X3D_LAUNCH_CHECK();
         return X3D_OK;
     }
-    // round 4: 16-wave workgroups for the K >= 320 layers (one workgroup per CU either way; fp32 storage)
-    if (!x_bf && !y_bf && per == 16 && A.mt_run <= 16 && kp <= 512 && x3d_opt(X3D_OPT_PW_WAVES16)) {
-#define P6_GO16(AFF)                                                                                                \
+    // round 4: 16-wave workgroups (fp32 storage).  pw_waves16 = 1: the K >= 320 layers (one workgroup per CU either way);
+    // = 2 (default): also every layer with more than 16 M tiles -- all M tiles of the layer (up to 32: two per wave) then
+    // share ONE staged activation tile instead of one per block of 8 tiles (stage 4 conv1 / conv3 data gradient: 27 tiles,
+    // four blocks: 15.0 -> 12.9 us, 19.3 -> 16.7 us); = 3: from 9 tiles on (stage 3's 14-tile layers: two blocks -> one --
+    // measured SLOWER, 19.9 -> 22.0 / 25.2 -> 30.5 us: half as many workgroups per CU cost more than the second staging)
+    const int w16 = x3d_opt(X3D_OPT_PW_WAVES16);
+    if (!x_bf && !y_bf && kp <= 512 && mtiles <= 32 && ((w16 >= 1 && per == 16 && mtiles <= 16) || (w16 >= 2 && mtiles > 16) || (w16 >= 3 && mtiles > 8))) {
+        A.mblocks = 1;
+        A.mt_run = mtiles;
+        const dim3 grid16(cdiv(VT, 8) * 8);
+#define P6_GO16(AFF, NP)                                                                                            \
     do {                                                                                                            \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw6_kernel<AFF, 4, false, 16>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 512 * P6_LD * 2);              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw6_kernel<AFF, NP, false, 16>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * NP * P6_LD * 2);         \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL((pw6_kernel<AFF, 4, false, 16>), grid, dim3(1024), lds, s, A);                            \
+        hipLaunchKernelGGL((pw6_kernel<AFF, NP, false, 16>), grid16, dim3(1024), lds, s, A);                         \
     } while (0)
+#define P6_NP16(AFF) do { if (kp <= 128) P6_GO16(AFF, 1); else if (kp <= 256) P6_GO16(AFF, 2); else P6_GO16(AFF, 4); } while (0)
         x3d_note_kernel("pw6_kernel");
-        if (cin) P6_GO16(1); else P6_GO16(0);
+        if (cin) P6_NP16(1); else P6_NP16(0);
+#undef P6_NP16
 #undef P6_GO16
         X3D_LAUNCH_CHECK();
         return X3D_OK;
@@ -1162,19 +1172,26 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
     do {                                                                                                             \
         if (npass <= 2) P7_GO(EPI_, 2, MX_); else if (npass <= 4) P7_GO(EPI_, 4, MX_); else P7_GO(EPI_, 7, MX_);     \
     } while (0)
-    if (!ga_bf && !y_bf && !ex_bf && ns == 3 && per == 16 && A.mt_run <= 16 && kp <= 512 && x3d_opt(X3D_OPT_PW_WAVES16)) {
-#define P7_GO16(EPI_)                                                                                               \
+    const int w16 = x3d_opt(X3D_OPT_PW_WAVES16);                      // 16-wave workgroups: see x3d_pw6_launch
+    if (!ga_bf && !y_bf && !ex_bf && ns == 3 && kp <= 512 && mtiles <= 32 &&
+        ((w16 >= 1 && per == 16 && mtiles <= 16) || (w16 >= 2 && mtiles > 16) || (w16 >= 3 && mtiles > 8))) {
+        A.mblocks = 1;
+        A.mt_run = mtiles;
+        const dim3 grid16(cdiv(VT, 8) * 8);
+#define P7_GO16(EPI_, NP)                                                                                           \
     do {                                                                                                            \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, 4, false, 3, 16>),             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 512 * P6_LD * 2);              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP, false, 3, 16>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * NP * P6_LD * 2);         \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL((pw7_kernel<EPI_, 4, false, 3, 16>), grid, dim3(1024), lds, s, A);                        \
+        hipLaunchKernelGGL((pw7_kernel<EPI_, NP, false, 3, 16>), grid16, dim3(1024), lds, s, A);                     \
     } while (0)
+#define P7_NP16(EPI_) do { if (kp <= 128) P7_GO16(EPI_, 1); else if (kp <= 256) P7_GO16(EPI_, 2); else P7_GO16(EPI_, 4); } while (0)
         x3d_note_kernel("pw7_kernel");
-        if (mode == P7_PLAIN) P7_GO16(P7_PLAIN); else if (mode == P7_ACTBWD) P7_GO16(P7_ACTBWD); else P7_GO16(P7_RESBWD);
+        if (mode == P7_PLAIN) P7_NP16(P7_PLAIN); else if (mode == P7_ACTBWD) P7_NP16(P7_ACTBWD); else P7_NP16(P7_RESBWD);
+#undef P7_NP16
 #undef P7_GO16
         X3D_LAUNCH_CHECK();
         return X3D_OK;
