@@ -607,7 +607,7 @@ def test_dw333_fwd_bwd(case):
 
 
 @pytest.mark.parametrize("case", [(8, 432, 16, 7, 7, 1), (2, 10, 16, 14, 14, 1), (2, 3, 8, 28, 28, 2), (1, 7, 9, 7, 7, 1),
-                                  (2, 40, 11, 5, 5, 2), (1, 2, 8, 40, 56, 1)])
+                                  (2, 40, 11, 5, 5, 2), (1, 2, 8, 40, 56, 1), (2, 5, 18, 14, 14, 2), (1, 3, 17, 7, 7, 1)])
 def test_dw333_t_segments_equal_the_single_march(case):
     """Launches with fewer workgroups than CUs cut the T march into two segments (options dw_tsplit_wgs / dw_tsplit_wgs_fwd: the 7 x 7
     planes of stage 4 at the base shape in both directions, the 14 x 14 planes of stage 3 forward).  Every output voxel is computed by the same arithmetic either way: y and dx BITWISE equal to
@@ -622,8 +622,8 @@ def test_dw333_t_segments_equal_the_single_march(case):
     g, a = to(_g(N, C, T, Ho, Wo, seed=5)), to(_g(N, C, T, Ho, Wo, seed=6))
     cb = to(torch.stack([1 + 0.1 * _g(N, C, seed=7), 0.1 * _g(N, C, seed=8), 0.05 * _g(N, C, seed=9)], -1))
 
-    def run(wgs):
-        with _lib.options(dw_tsplit_wgs=wgs, dw_tsplit_wgs_fwd=wgs):
+    def run(wgs, quad=0):
+        with _lib.options(dw_tsplit_wgs=wgs, dw_tsplit_wgs_fwd=wgs, dw_tquad_wgs=quad, dw_tquad_wgs_fwd=quad):
             y, p = ops.dw333_fwd(x, w, stride=s, pre=pre, pre_act=1)
             dx, dw, bp = ops.dw333_bwd(g, a, cb, w, x, stride=s, pre=pre, pre_act=1)
             return y, p, dx, dw, bp
@@ -633,6 +633,12 @@ def test_dw333_t_segments_equal_the_single_march(case):
     assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
     assert _rel(p1.double().sum(2), p0.double().sum(2)) < 1e-6 and _rel(bp1.double().sum(2), bp0.double().sum(2)) < 1e-6
     assert _rel(dw1, dw0) < 1e-6
+    if T >= 16:                                              # round 4: four segments (options dw_tquad_wgs[_fwd])
+        y2, p2, dx2, dw2, bp2 = run(1 << 20, 1 << 20)
+        assert p2.shape[2] == 4 * p0.shape[2] and bp2.shape[2] == 4 * bp0.shape[2]
+        assert torch.equal(y0, y2) and torch.equal(dx0, dx2)
+        assert _rel(p2.double().sum(2), p0.double().sum(2)) < 1e-6 and _rel(bp2.double().sum(2), bp0.double().sum(2)) < 1e-6
+        assert _rel(dw2, dw0) < 1e-6
 
 
 @pytest.mark.parametrize("case", DW_CASES)

@@ -62,6 +62,8 @@ const OptDef kOpts[X3D_OPT_COUNT] = {
     /* X3D_OPT_PW9_MAX_K      */ {"pw9_max_k", "X3D_PW9_MAX_K", 0, 0},
     /* X3D_OPT_NO_SE_BWD_MERGE */ {"no_se_bwd_merge", "X3D_NO_SE_BWD_MERGE", 0, 1},
     /* X3D_OPT_PW_WAVES16     */ {"pw_waves16", "X3D_PW_WAVES16", 2, 0},
+    /* X3D_OPT_DW_TQUAD_WGS   */ {"dw_tquad_wgs", "X3D_DW_TQUAD_WGS", 0, 0},
+    /* X3D_OPT_DW_TQUAD_WGS_FWD */ {"dw_tquad_wgs_fwd", "X3D_DW_TQUAD_WGS_FWD", 0, 0},
 };
 std::atomic<int> g_opt[X3D_OPT_COUNT];
 std::once_flag g_opt_once;
@@ -93,6 +95,7 @@ bool opt_valid(int id, int v) {
     switch (id) {
         case X3D_OPT_FB_GRID: case X3D_OPT_PW_PGRID: case X3D_OPT_WG_CAP: case X3D_OPT_STEM_WG_CAP: return v >= 1 && v <= 65535;
         case X3D_OPT_PW_NT4_MIN: case X3D_OPT_DW_TSPLIT_WGS: case X3D_OPT_DW_TSPLIT_WGS_FWD: return v >= 0;
+        case X3D_OPT_DW_TQUAD_WGS: case X3D_OPT_DW_TQUAD_WGS_FWD: return v >= 0;
         case X3D_OPT_PW8_GRID: return v >= 0 && v <= 65535;
         case X3D_OPT_PW8_MAX_K: case X3D_OPT_PW9_MAX_K: return v >= 0 && v <= 224;
         case X3D_OPT_PW_WAVES16: return v >= 0 && v <= 3;

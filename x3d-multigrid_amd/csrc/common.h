@@ -41,6 +41,8 @@ enum X3DOpt {
     X3D_OPT_PW9_MAX_K,        // largest padded K the persistent DATA-GRADIENT kernel pw9 takes (0 = never: it does not pay)  0
     X3D_OPT_NO_SE_BWD_MERGE,  // separate reduce_tiles + se_bwd_sample launches instead of the merged per-sample kernel  0
     X3D_OPT_PW_WAVES16,       // whole-K kernels pw6 / pw7, 16-wave workgroups: 0 never, 1 K >= 320, 2 also > 16 M tiles, 3 also > 8   2
+    X3D_OPT_DW_TQUAD_WGS,     // channelwise backward: launches whose TWO-segment form has at most this many workgroups use four  0
+    X3D_OPT_DW_TQUAD_WGS_FWD, // the same for the forward kernel                                                           0
     X3D_OPT_COUNT
 };
 int x3d_opt(int id);

@@ -73,6 +73,9 @@ static DwGeom make_geom(int N, int C, int T, int H, int W, int stride, bool back
     // the forward kernel's pay there: 16.9 -> 14.7 us -- separate thresholds)
     const int split_wgs = x3d_opt(backward ? X3D_OPT_DW_TSPLIT_WGS : X3D_OPT_DW_TSPLIT_WGS_FWD);
     if (T >= 8 && wgs <= (long long)split_wgs) { g.tsegs = 2; g.tlen = cdiv(T, 2); }
+    // round 4: FOUR segments where two still leave fewer workgroups than `quad_wgs` (option dw_tquad_wgs[_fwd]; T >= 16)
+    const int quad_wgs = x3d_opt(backward ? X3D_OPT_DW_TQUAD_WGS : X3D_OPT_DW_TQUAD_WGS_FWD);
+    if (T >= 16 && 2 * wgs <= (long long)quad_wgs) { g.tsegs = 4; g.tlen = cdiv(T, 4); }
     return g;
 }
 
