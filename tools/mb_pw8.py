@@ -1,5 +1,5 @@
 """Whole-K pointwise kernels of stages 3-4 at the headline shape: non-persistent pw6 / pw7 (option no_pw8) against the
-persistent producer / consumer kernels pw8 / pw9, `reps` dependent launches captured in one hipGraph (a dependent launch of
+persistent producer / consumer kernel pw8, `reps` dependent launches captured in one hipGraph (a dependent launch of
 the replayed graph costs ~4.7 us by itself; the figure here includes it).   python tools/mb_pw8.py [reps]"""
 import os
 import sys
@@ -52,7 +52,7 @@ for name, N, Ci, Co, T, H, act in LAYERS:
     xo_ = torch.relu(torch.randn(N, Ci, T, H, H, device=dev)); ex = torch.randn(N, Ci, T, H, H, device=dev)
     pre2 = torch.rand(N, Ci, 2, device=dev) + 0.5
     res = {}
-    for tag, opts in (("pw7 8w", dict(no_pw8=1, pw_waves16=0)), ("pw7", dict(no_pw8=1)), ("pw7 w16=3", dict(no_pw8=1, pw_waves16=3)), ("pw9", dict(pw9_max_k=224))):
+    for tag, opts in (("pw7 8w", dict(no_pw8=1, pw_waves16=0)), ("pw7", dict(no_pw8=1)), ("pw7 w16=3", dict(no_pw8=1, pw_waves16=3))):
         with _lib.options(**opts):
             ta = t(lambda: ops.pw_bwd_data(g, a, cb, w, x=ex, pre=pre2, pre_act=2, wpt=wpt))
             ka = _lib.last_kernel()

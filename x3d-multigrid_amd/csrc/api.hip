@@ -59,7 +59,6 @@ const OptDef kOpts[X3D_OPT_COUNT] = {
     /* X3D_OPT_NO_PW8         */ {"no_pw8", "X3D_NO_PW8", 0, 1},
     /* X3D_OPT_PW8_GRID       */ {"pw8_grid", "X3D_PW8_GRID", 0, 0},
     /* X3D_OPT_PW8_MAX_K      */ {"pw8_max_k", "X3D_PW8_MAX_K", 128, 0},
-    /* X3D_OPT_PW9_MAX_K      */ {"pw9_max_k", "X3D_PW9_MAX_K", 0, 0},
     /* X3D_OPT_NO_SE_BWD_MERGE */ {"no_se_bwd_merge", "X3D_NO_SE_BWD_MERGE", 0, 1},
     /* X3D_OPT_PW_WAVES16     */ {"pw_waves16", "X3D_PW_WAVES16", 2, 0},
     /* X3D_OPT_DW_TQUAD_WGS   */ {"dw_tquad_wgs", "X3D_DW_TQUAD_WGS", 0, 0},
@@ -97,7 +96,7 @@ bool opt_valid(int id, int v) {
         case X3D_OPT_PW_NT4_MIN: case X3D_OPT_DW_TSPLIT_WGS: case X3D_OPT_DW_TSPLIT_WGS_FWD: return v >= 0;
         case X3D_OPT_DW_TQUAD_WGS: case X3D_OPT_DW_TQUAD_WGS_FWD: return v >= 0;
         case X3D_OPT_PW8_GRID: return v >= 0 && v <= 65535;
-        case X3D_OPT_PW8_MAX_K: case X3D_OPT_PW9_MAX_K: return v >= 0 && v <= 224;
+        case X3D_OPT_PW8_MAX_K: return v >= 0 && v <= 224;
         case X3D_OPT_PW_WAVES16: return v >= 0 && v <= 3;
         case X3D_OPT_DW_TH: case X3D_OPT_DW_CPB_MAX: return v >= 1 && v <= 16;
         case X3D_OPT_WG_CPW: return v >= 1 && v <= 4096;

@@ -35,10 +35,9 @@ enum X3DOpt {
     X3D_OPT_PW6_MIN_M,        // whole-K forward kernel pw6: smallest output-channel count it takes                96
     X3D_OPT_PW_TWO_TILES_K,   // whole-K kernels: padded K from which a wave takes two M tiles of one staged tile  320
     X3D_OPT_DW_TSPLIT_WGS_FWD,  // the same threshold for the forward channelwise kernel (14 x 14 planes: 16.9 -> 14.7 us)  512
-    X3D_OPT_NO_PW8,           // round 4: non-persistent pw6 / pw7 instead of the producer / consumer kernels pw8 / pw9  0
+    X3D_OPT_NO_PW8,           // round 4: non-persistent pw6 instead of the producer / consumer forward kernel pw8          0
     X3D_OPT_PW8_GRID,         // workgroups of the persistent producer / consumer kernels (0 = one per CU)           0
     X3D_OPT_PW8_MAX_K,        // largest padded K the persistent FORWARD kernel pw8 takes (0 = never; it wins at K <= 128)   128
-    X3D_OPT_PW9_MAX_K,        // largest padded K the persistent DATA-GRADIENT kernel pw9 takes (0 = never: it does not pay)  0
     X3D_OPT_NO_SE_BWD_MERGE,  // separate reduce_tiles + se_bwd_sample launches instead of the merged per-sample kernel  0
     X3D_OPT_PW_WAVES16,       // whole-K kernels pw6 / pw7, 16-wave workgroups: 0 never, 1 K >= 320, 2 also > 16 M tiles, 3 also > 8   2
     X3D_OPT_DW_TQUAD_WGS,     // channelwise backward: launches whose TWO-segment form has at most this many workgroups use four  0
@@ -70,6 +69,11 @@ __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / 
 // ---------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------
+
+// Workgroup barrier that orders LDS only.  __syncthreads() compiles to "s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier": it also
+// drains every global load a wave has in flight (the next chunk's prefetch) and every output store it has issued.  Where a
+// workgroup never reads global memory it wrote itself, only the LDS needs ordering.
+__device__ __forceinline__ void x3d_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Sum over the 16 lanes of a DPP row (lanes 16k..16k+15); every lane of the row gets the total.
 // quad_perm / row_half_mirror / row_mirror butterflies: 4 VALU ops, no LDS.

@@ -169,12 +169,16 @@ __global__ __launch_bounds__(64 * NW, 4) void pw6_kernel(const P6Args A) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             const bf16x8 bh = tr_frag(Xh, s, h2), bm = tr_frag(Xm, s, h2), bl = tr_frag(Xl, s, h2);
-            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l, bh, acc[h2], 0, 0, 0);
-            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bl, acc[h2], 0, 0, 0);
-            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m, bm, acc[h2], 0, 0, 0);
-            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m, bh, acc[h2], 0, 0, 0);
-            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bm, acc[h2], 0, 0, 0);
-            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, bh, acc[h2], 0, 0, 0);
+            // round 4: the ACTIVATION fragment is the A operand (rows = voxels) and the weight fragment the B operand (the two
+            // fragment layouts are the same), so the accumulator holds the TRANSPOSED tile: lane (q, r) owns channel r and
+            // the voxels of rows 4 q + e -- with the interleaved LDS columns 8 consecutive voxels: two 16-byte stores per
+            // M tile instead of four 8-byte ones, statistics = in-lane sums + two cross-row steps instead of 4 x 8 DPP adds
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, l, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, h, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, m, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, m, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, h, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, h, acc[h2], 0, 0, 0);
         }
     };
     for (int pass = 0; pass < 2; ++pass) {
@@ -200,22 +204,33 @@ __global__ __launch_bounds__(64 * NW, 4) void pw6_kernel(const P6Args A) {
         }
 
         P6T(5);
-        // ---- epilogue: lane (q, r) holds rows 4 q + e of the tile and voxels 2 r (acc[0]), 2 r + 1 (acc[1])
-        const int pl = pt + 2 * r;
-        const bool pv = pl < P;                   // P even: both voxels or none
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = mt * 16 + 4 * q + e;
+        // ---- epilogue: lane (q, r) holds channel mt * 16 + r and the 8 voxels pt + 8 q + j: acc[j & 1][j >> 1]
+        // (voxel v of the tile sits at LDS column (v & 1) * 16 + (v >> 1); accumulator row 4 q + e of half h2 = column)
+        {
+            const int m = mt * 16 + r;
             const bool mv = m < M;
-            const float v0 = stored(pv ? acc[0][e] : 0.f, y_bf), v1 = stored(pv ? acc[1][e] : 0.f, y_bf);
-            if (mv && pv) stx2(A.y, ((size_t)n * M + m) * (size_t)P + pl, y_bf, v0, v1);
+            const int p0 = pt + 8 * q;
+            const bool pva = p0 < P, pvb = p0 + 4 < P;            // P % 4 == 0: whole groups of four
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = stored(((j < 4) ? pva : pvb) ? acc[j & 1][j >> 1] : 0.f, y_bf);
+            const size_t yo = ((size_t)n * M + (mv ? m : 0)) * (size_t)P + p0;
+            if (mv && pva) {
+                if (y_bf) { stx2(A.y, yo, 1, v[0], v[1]); stx2(A.y, yo + 2, 1, v[2], v[3]); }
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(A.y) + yo) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (mv && pvb) {
+                if (y_bf) { stx2(A.y, yo + 4, 1, v[4], v[5]); stx2(A.y, yo + 6, 1, v[6], v[7]); }
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(A.y) + yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
             if (A.partial != nullptr) {
-                const float s1 = row16_sum(v0 + v1);
-                const float s2 = row16_sum(fmaf(v0, v0, v1 * v1));
-                if (r == 0 && mv) {
-                    float* pp = A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2;
-                    pp[0] = s1; pp[1] = s2;
-                }
+                float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                float s2 = fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+                s2 += fmaf(v[4], v[4], v[5] * v[5]) + fmaf(v[6], v[6], v[7] * v[7]);
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (q == 0 && mv)
+                    *reinterpret_cast<float2*>(A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2) = make_float2(s1, s2);
             }
         }
       }
@@ -413,12 +428,13 @@ __global__ __launch_bounds__(P8_NT, 1) void pw8_kernel(const P6Args A) {
 #pragma unroll
                         for (int j = 0; j < TPW; ++j) {
                             if (j == 0 || tok[j]) {                  // smallest terms first, as pw6_kernel
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j][slot], bh, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bl, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j][slot], bm, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j][slot], bh, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bm, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bh, acc[j][h2], 0, 0, 0);
+                                // (activation fragment = A operand: transposed accumulator tile, see pw6_kernel)
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[j][slot], acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[j][slot], acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[j][slot], acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[j][slot], acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[j][slot], acc[j][h2], 0, 0, 0);
+                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[j][slot], acc[j][h2], 0, 0, 0);
                             }
                         }
                     }
@@ -428,26 +444,28 @@ __global__ __launch_bounds__(P8_NT, 1) void pw8_kernel(const P6Args A) {
                     }
                 }
             }
-            // ---- epilogue: lane (q, r) holds rows 4 q + e of a tile and voxels 2 r (acc[.][0]), 2 r + 1 (acc[.][1])
-            const int pl = pt0 + 2 * r;
-            const bool pv = valid && pl < P;                         // P even: both voxels or none
+            // ---- epilogue: lane (q, r) holds channel mt * 16 + r and the 8 voxels pt0 + 8 q + j: acc[.][j & 1][j >> 1]
+            const int p0 = pt0 + 8 * q;
+            const bool pva = valid && p0 < P, pvb = valid && p0 + 4 < P;      // P % 4 == 0: whole groups of four
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
                 if (j == 0 || tok[j]) {
+                    const int m = mt[j] * 16 + r;
+                    const bool mv = m < M;
+                    float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int m = mt[j] * 16 + 4 * q + e;
-                        const bool mv = m < M;
-                        const float v0 = pv ? acc[j][0][e] : 0.f, v1 = pv ? acc[j][1][e] : 0.f;
-                        if (mv && pv) *reinterpret_cast<float2*>(reinterpret_cast<float*>(A.y) + ((size_t)n * M + m) * (size_t)P + pl) = make_float2(v0, v1);
-                        if (A.partial != nullptr) {
-                            const float s1 = row16_sum(v0 + v1);
-                            const float s2 = row16_sum(fmaf(v0, v0, v1 * v1));
-                            if (r == 0 && mv && valid) {
-                                float* pp = A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2;
-                                pp[0] = s1; pp[1] = s2;
-                            }
-                        }
+                    for (int jj = 0; jj < 8; ++jj) v[jj] = ((jj < 4) ? pva : pvb) ? acc[j][jj & 1][jj >> 1] : 0.f;
+                    float* yp = reinterpret_cast<float*>(A.y) + ((size_t)n * M + (mv ? m : 0)) * (size_t)P + p0;
+                    if (mv && pva) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (mv && pvb) *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    if (A.partial != nullptr) {
+                        float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                        float s2 = fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+                        s2 += fmaf(v[4], v[4], v[5] * v[5]) + fmaf(v[6], v[6], v[7] * v[7]);
+                        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                        if (q == 0 && mv && valid)
+                            *reinterpret_cast<float2*>(A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2) = make_float2(s1, s2);
                     }
                 }
             }
@@ -482,8 +500,253 @@ struct P7Args {
 // NS: bf16 terms per fp32 operand -- 3 (hi + mid + lo = all 24 significant bits, six MFMA products: fp32-level, as pw6; the
 // default) or 2 (hi + lo, three products, ~2^-16 per product; option bwd_terms = 2).  The transposed pack always carries
 // three planes; the two-term form reads hi and mid (mid = bf16(v - hi) is exactly its "lo").
-template <int EPI, int NPASS, bool MX, int NS, int NW = 8>      // NW: waves per workgroup, see pw6_kernel
+// ADD2: the addend is the stride-(1,2,2) gradient of a downsample branch (4 launches per step): only that instantiation carries
+// the (t, h, w) walk of the lane's 8 voxels -- ~18 registers the common variants, already at the 128-register cap, do not have.
+template <int EPI, int NPASS, bool MX, int NS, int NW = 8, bool ADD2 = false>      // NW: waves per workgroup, see pw6_kernel
 __global__ __launch_bounds__(64 * NW, (NW == 16 || NPASS <= 4) ? 4 : 2) void pw7_kernel(const P7Args A) {
+    const int ga_bf = MX ? A.ga_bf : 0, y_bf = MX ? A.y_bf : 0, ex_bf = MX ? A.ex_bf : 0;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int K = A.K, P = A.P, M = A.M;
+    const int kg32 = (K + 31) / 32, kg16 = (K + 15) / 16, Kp = kg32 * 32;
+    __bf16* Dh = lds6;
+    __bf16* Dm = lds6 + (size_t)Kp * P6_LD;                   // NS = 2: the second (last) plane
+    __bf16* Dl = lds6 + (size_t)(NS - 1) * Kp * P6_LD;
+
+    const int VT = A.N * A.tiles;
+    const int it = blockIdx.x;
+    const int tlo = it & 7, rest = it >> 3;
+    const int mb = rest % A.mblocks, vt = (rest / A.mblocks) * 8 + tlo;
+    if (vt >= VT) return;
+    const int n = vt / A.tiles, tile = vt - n * A.tiles;
+    const int pt = tile * P6_BN;
+
+    // ---- stage dY: whole K x 32 voxels of g and a in one burst
+    {
+        const int c4 = (tid & 7) * 4, row0 = tid >> 3;
+        constexpr int RP = 8 * NW;
+        const int pc = min(pt + c4, P - 4);
+        const bool pvv = pt + c4 < P;
+        const int colE = c4 >> 1, colO = colE + 16;
+        const char* gs = mx_base(A.g, (size_t)n * K * (size_t)P, ga_bf);
+        const char* as = mx_base(A.a, (size_t)n * K * (size_t)P, ga_bf);
+        const float* cs = A.cb + (size_t)n * K * 3;
+        float4 rg[NPASS], ra[NPASS];
+        float k0[NPASS], k1[NPASS], k2[NPASS];
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const unsigned k = (unsigned)min(row0 + RP * i, K - 1);
+            const unsigned off = k * (unsigned)P + (unsigned)pc;
+            rg[i] = ldo4_raw(gs, off, ga_bf);
+            ra[i] = ldo4_raw(as, off, ga_bf);
+            const float* c3 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(cs) + k * 12u);
+            k0[i] = c3[0]; k1[i] = c3[1]; k2[i] = c3[2];
+        }
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int row = row0 + RP * i;
+            if (row < Kp) {
+                const bool ok = pvv && row < K;
+                const float4 gw = widen4(rg[i], ga_bf), aw = widen4(ra[i], ga_bf);
+                const float gv[4] = {gw.x, gw.y, gw.z, gw.w}, av[4] = {aw.x, aw.y, aw.z, aw.w};
+                float xs[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xs[e] = ok ? fmaf(k0[i], gv[e], fmaf(k1[i], av[e], k2[i])) : 0.f;
+                unsigned hE, mE, lE, hO, mO, lO;               // pairs (0, 2) and (1, 3): x3d_split3_pair, common.h
+                x3d_split3_pair(xs[0], xs[2], hE, mE, lE);
+                x3d_split3_pair(xs[1], xs[3], hO, mO, lO);
+                const bf16x2 he = __builtin_bit_cast(bf16x2, hE), ho = __builtin_bit_cast(bf16x2, hO);
+                const bf16x2 me = __builtin_bit_cast(bf16x2, mE), mo = __builtin_bit_cast(bf16x2, mO);
+                const bf16x2 le = __builtin_bit_cast(bf16x2, lE), lo = __builtin_bit_cast(bf16x2, lO);
+                *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colE]) = he;
+                *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colO]) = ho;
+                *reinterpret_cast<bf16x2*>(&Dm[row * P6_LD + colE]) = me;
+                *reinterpret_cast<bf16x2*>(&Dm[row * P6_LD + colO]) = mo;
+                if (NS == 3) {
+                    *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colE]) = le;
+                    *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colO]) = lo;
+                }
+            }
+        }
+    }
+
+    // (the staging registers -- 8 NPASS floats of g and a -- are dead here; keep the scheduler from hoisting the A-fragment
+    // and epilogue-operand requests above the staging: that is what pushes the allocation past 128 registers)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- this wave's A fragments (first ring entries), then the epilogue operands: both in flight across the barrier
+    const int mtiles = (M + 15) / 16;
+    // (blocks of more than 8 tiles -- large K, x3d_pw7_launch -- give wave w the tiles w and w + 8 of ONE staged dY tile)
+    int mt = min(mb * A.mt_run + wave, mtiles - 1);                            // clamped: a duplicate is never stored
+    bool mt_ok = wave < A.mt_run && mb * A.mt_run + wave < mtiles;
+    const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
+    const size_t plane = (size_t)mtiles * kg32 * 512;
+    const __bf16* wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;
+    constexpr int RING = (EPI == P7_PLAIN || NPASS > 4) ? 4 : 3;   // A-fragment ring depth: three where the epilogue operands need the registers
+    bf16x8 ah[RING], am[RING], al[RING];
+    auto fetch_a = [&](int s, bf16x8& h, bf16x8& m, bf16x8& l) {
+        const int sc = min(s, kg32 - 1);
+        h = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512);
+        m = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512 + plane);
+        if (NS == 3) l = *reinterpret_cast<const bf16x8*>(wa + (size_t)sc * 512 + 2 * plane);
+    };
+#pragma unroll
+    for (int i = 0; i < RING; ++i) fetch_a(i, ah[i], am[i], al[i]);
+
+    // lane (q, r) of the TRANSPOSED accumulator tile (activation fragment = A operand, see pw6_kernel): channel mt * 16 + r,
+    // the 8 consecutive voxels pt + 8 q + j = acc[j & 1][j >> 1]
+    const int p0 = pt + 8 * q;
+    const bool pva = p0 < P, pvb = p0 + 4 < P;    // P % 4 == 0: whole groups of four
+    const int pca = pva ? p0 : 0, pcb = pvb ? p0 + 4 : 0;
+    const bool has_add = A.addend != nullptr;
+    const bool add_s2 = ADD2 && has_add && A.addend_stride == 2;
+    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
+    float xv[8], mk[8], adv[8], esc1 = 1.f, esh1 = 0.f;
+    auto fetch_epi = [&]() {                      // epilogue operands of tile mt: requested behind its first A fragments
+        const int m = mt * 16 + r;
+        const size_t mrow = (size_t)n * M + (m < M ? m : 0);
+        if (EPI == P7_ACTBWD) {
+            const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
+            esc1 = c2.x; esh1 = c2.y;
+        }
+        if (EPI != P7_PLAIN) {
+            if (MX && ex_bf) {                    // raw bf16 pairs, widened in the epilogue
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2 t2 = ldx2_raw(A.ex, mrow * (size_t)P + ((j < 2) ? pca : pcb) + 2 * (j & 1), 1);
+                    xv[2 * j] = t2.x; xv[2 * j + 1] = t2.y;
+                }
+            } else {
+                const float* px = reinterpret_cast<const float*>(A.ex) + mrow * (size_t)P;
+                const float4 ta = *reinterpret_cast<const float4*>(px + pca), tb = *reinterpret_cast<const float4*>(px + pcb);
+                xv[0] = ta.x; xv[1] = ta.y; xv[2] = ta.z; xv[3] = ta.w; xv[4] = tb.x; xv[5] = tb.y; xv[6] = tb.z; xv[7] = tb.w;
+            }
+        }
+        if (EPI == P7_RESBWD) {
+            const float* pm = A.emask + mrow * (size_t)P;
+            const float4 ta = *reinterpret_cast<const float4*>(pm + pca), tb = *reinterpret_cast<const float4*>(pm + pcb);
+            mk[0] = ta.x; mk[1] = ta.y; mk[2] = ta.z; mk[3] = ta.w; mk[4] = tb.x; mk[5] = tb.y; mk[6] = tb.z; mk[7] = tb.w;
+        }
+        if (has_add) {
+            const float* pa = A.addend + mrow * (size_t)addP;
+            if (!ADD2 || !add_s2) {
+                const float4 ta = *reinterpret_cast<const float4*>(pa + pca), tb = *reinterpret_cast<const float4*>(pa + pcb);
+                adv[0] = ta.x; adv[1] = ta.y; adv[2] = ta.z; adv[3] = ta.w; adv[4] = tb.x; adv[5] = tb.y; adv[6] = tb.z; adv[7] = tb.w;
+            } else {                              // stride-2 addend (downsample blocks): walk the 8 voxels' (t, h, w)
+                const int hw = A.H * A.W;
+                int t = pca / hw;
+                const int rem = pca - t * hw;
+                int h = rem / A.W, w = rem - h * A.W;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = ((j < 4) ? pva : pvb) && !(h & 1) && !(w & 1);
+                    const float a = pa[ok ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0];
+                    adv[j] = ok ? a : 0.f;
+                    if (++w == A.W) { w = 0; if (++h == A.H) { h = 0; ++t; } }
+                }
+            }
+        }
+    };
+    fetch_epi();
+    p8_barrier();
+
+    f32x4 acc[2];
+    const int tr_off = (8 * q + (r >> 2)) * P6_LD + 4 * (r & 3);
+    auto tr_frag = [&](const __bf16* pln, int s, int h2) -> bf16x8 {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const __bf16* p0 = pln + 32 * s * P6_LD + tr_off + 16 * h2;
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * P6_LD));
+        return cat8_(v0, v1);
+    };
+    auto step = [&](int s, const bf16x8& h, const bf16x8& m, const bf16x8& l) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const bf16x8 bh = tr_frag(Dh, s, h2), bm = tr_frag(Dm, s, h2);
+            if (NS == 3) {                        // smallest terms first, as pw6
+                const bf16x8 bl = tr_frag(Dl, s, h2);
+                acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, l, acc[h2], 0, 0, 0);
+                acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, h, acc[h2], 0, 0, 0);
+                acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, m, acc[h2], 0, 0, 0);
+            }
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, m, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, h, acc[h2], 0, 0, 0);
+            acc[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, h, acc[h2], 0, 0, 0);
+        }
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) {                            // second tile of this wave (blocks of more than 8 tiles): w + 8
+        if (A.mt_run <= NW) break;
+        mt_ok = wave + NW < A.mt_run && mb * A.mt_run + wave + NW < mtiles;
+        if (!mt_ok) break;
+        mt = mb * A.mt_run + wave + NW;
+        wa = wq + ((size_t)mt * kg32 * 64 + lane) * 8;
+#pragma unroll
+        for (int i = 0; i < RING; ++i) fetch_a(i, ah[i], am[i], al[i]);
+        fetch_epi();
+      }
+      if (mt_ok) {
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < kg32; s0 += RING) {
+#pragma unroll
+            for (int i = 0; i < RING; ++i) {
+                if (s0 + i < kg32) {
+                    step(s0 + i, ah[i], am[i], al[i]);
+                    if (s0 + i + RING < kg32) fetch_a(s0 + i + RING, ah[i], am[i], al[i]);
+                }
+            }
+        }
+        {
+            const int m = mt * 16 + r;
+            const bool mv = m < M;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = acc[j & 1][j >> 1] + (has_add ? adv[j] : 0.f);     // (invalid voxels: masked / not stored)
+            float s1 = 0.f, s2 = 0.f;
+            if (EPI != P7_PLAIN) {
+                float xw[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2 t2 = widen2(make_float2(xv[2 * j], xv[2 * j + 1]), (MX && EPI == P7_ACTBWD) ? ex_bf : 0);
+                    xw[2 * j] = t2.x; xw[2 * j + 1] = t2.y;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool pj = (j < 4) ? pva : pvb;
+                    const float xj = pj ? xw[j] : 0.f;
+                    if (EPI == P7_RESBWD) v[j] = (pj && mk[j] > 0.f) ? v[j] : 0.f;
+                    else v[j] = pj ? v[j] * act_bwd(fmaf(esc1, xj, esh1), A.e_act) : 0.f;
+                    v[j] = stored(v[j], y_bf);
+                    s1 += v[j];
+                    s2 = fmaf(v[j], xj, s2);
+                }
+            }
+            const size_t yo = ((size_t)n * M + (mv ? m : 0)) * (size_t)P + p0;
+            if (mv && pva) {
+                if (y_bf) { stx2(A.y, yo, 1, v[0], v[1]); stx2(A.y, yo + 2, 1, v[2], v[3]); }
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(A.y) + yo) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (mv && pvb) {
+                if (y_bf) { stx2(A.y, yo + 4, 1, v[4], v[5]); stx2(A.y, yo + 6, 1, v[6], v[7]); }
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(A.y) + yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (EPI != P7_PLAIN && A.partial != nullptr) {
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (q == 0 && mv)
+                    *reinterpret_cast<float2*>(A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2) = make_float2(s1, s2);
+            }
+        }
+      }
+    }
+}
+
+// The ROW-wise form of the kernel above (round 3's epilogue: lane (q, r) = rows 4 q + e, voxels 2 r, 2 r + 1), kept for the
+// residual-backward mode only: with three 8-voxel epilogue operands (raw a3, ReLU mask, addend) the transposed form needs
+// ~150 registers and spills at the 128-register cap (measured 22.9 -> 24.5 us); this one fits with the 4-deep A ring.
+template <int EPI, int NPASS, bool MX, int NS, int NW = 8>
+__global__ __launch_bounds__(64 * NW, (NW == 16 || NPASS <= 4) ? 4 : 2) void pw7r_kernel(const P7Args A) {
     const int ga_bf = MX ? A.ga_bf : 0, y_bf = MX ? A.y_bf : 0, ex_bf = MX ? A.ex_bf : 0;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -702,281 +965,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || NPASS <= 4) ? 4 : 2) void pw7
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Round 4: persistent producer / consumer form of pw7_kernel (three-term operands, fp32 storage), the skeleton of
-// pw8_kernel: producers stage dY = cb0 g + cb1 a + cb2 of item i + 1 (g and a requested one item ahead in two register
-// sets), consumers run the MFMA loop of item i with resident / ring A fragments of the TRANSPOSED pack and the epilogue
-// (activation backward / residual backward / addend, statistics, stores); the epilogue's operands are requested in front of
-// the barrier, so they land while the consumers wait for the buffer and run the K loop.  Same products in the same order
-// as pw7_kernel<.., NS = 3>: bitwise the same dX and statistics tiles.
-// ---------------------------------------------------------------------------------------
-template <int EPI, int KG, int TPW>
-__global__ __launch_bounds__(P8_NT, 1) void pw9_kernel(const P7Args A) {
-    constexpr int RD = P8Ring<KG, TPW>::RD;
-    extern __shared__ __attribute__((aligned(16))) __bf16 lds6[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = A.K, P = A.P, M = A.M;
-    const int kg32 = (K + 31) / 32, kg16 = (K + 15) / 16, Kp = kg32 * 32;
-    const size_t bufsz = (size_t)3 * Kp * P6_LD;
-    const int VT = A.N * A.tiles, VT8 = (VT + 7) & ~7;
-    const int items = VT8 * A.mblocks;
-    const int G = (int)gridDim.x;
-    const int niter = (items - (int)blockIdx.x + G - 1) / G;
 
-    if (wave >= 8) {
-        // ------------------------------------------------ producers
-        const int pt = tid - P8_PROD0;
-        const int c4 = (pt & 7) * 4, row0 = pt >> 3;
-        const int colE = c4 >> 1, colO = colE + 16;
-        float4 rga[KG], raa[KG], rgb[KG], rab[KG];
-        int na = 0, nb = 0;
-        bool pva = false, pvb = false;
-        auto issue = [&](int i, float4 (&rg)[KG], float4 (&ra)[KG], int& nn, bool& pvv) {
-            const int it = (int)blockIdx.x + i * G;
-            const int mb = it / VT8;
-            const int vt = min(it - mb * VT8, VT - 1);
-            const int n = vt / A.tiles, tile = vt - n * A.tiles;
-            const int pt0 = tile * P6_BN;
-            const int pc = min(pt0 + c4, P - 4);
-            pvv = pt0 + c4 < P;
-            nn = n;
-            const float* gs = reinterpret_cast<const float*>(A.g) + (size_t)n * K * (size_t)P;
-            const float* as = reinterpret_cast<const float*>(A.a) + (size_t)n * K * (size_t)P;
-#pragma unroll
-            for (int j = 0; j < KG; ++j) {
-                const unsigned k = (unsigned)min(row0 + P8_RP * j, K - 1);
-                const size_t off = (size_t)k * (unsigned)P + (unsigned)pc;
-                rg[j] = *reinterpret_cast<const float4*>(gs + off);
-                ra[j] = *reinterpret_cast<const float4*>(as + off);
-            }
-        };
-        auto stage = [&](int i, const float4 (&rg)[KG], const float4 (&ra)[KG], int n, bool pvv) {
-            __bf16* Dh = lds6 + (size_t)(i & 1) * bufsz;
-            __bf16* Dm = Dh + (size_t)Kp * P6_LD;
-            __bf16* Dl = Dm + (size_t)Kp * P6_LD;
-            const float* cs = A.cb + (size_t)n * K * 3;
-            float k0[KG], k1[KG], k2[KG];                            // (L2-resident, 12 B per row: requested at use)
-#pragma unroll
-            for (int j = 0; j < KG; ++j) {
-                const unsigned k = (unsigned)min(row0 + P8_RP * j, K - 1);
-                const float* c3 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(cs) + k * 12u);
-                k0[j] = c3[0]; k1[j] = c3[1]; k2[j] = c3[2];
-            }
-#pragma unroll
-            for (int j = 0; j < KG; ++j) {
-                const int row = row0 + P8_RP * j;
-                if (row < Kp) {
-                    const bool ok = pvv && row < K;
-                    const float gv[4] = {rg[j].x, rg[j].y, rg[j].z, rg[j].w}, av[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
-                    float xs[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) xs[e] = ok ? fmaf(k0[j], gv[e], fmaf(k1[j], av[e], k2[j])) : 0.f;
-                    unsigned hE, mE, lE, hO, mO, lO;
-                    x3d_split3_pair(xs[0], xs[2], hE, mE, lE);
-                    x3d_split3_pair(xs[1], xs[3], hO, mO, lO);
-                    *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colE]) = __builtin_bit_cast(bf16x2, hE);
-                    *reinterpret_cast<bf16x2*>(&Dh[row * P6_LD + colO]) = __builtin_bit_cast(bf16x2, hO);
-                    *reinterpret_cast<bf16x2*>(&Dm[row * P6_LD + colE]) = __builtin_bit_cast(bf16x2, mE);
-                    *reinterpret_cast<bf16x2*>(&Dm[row * P6_LD + colO]) = __builtin_bit_cast(bf16x2, mO);
-                    *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colE]) = __builtin_bit_cast(bf16x2, lE);
-                    *reinterpret_cast<bf16x2*>(&Dl[row * P6_LD + colO]) = __builtin_bit_cast(bf16x2, lO);
-                }
-            }
-        };
-        issue(0, rga, raa, na, pva);
-        if (KG <= 4) {
-            for (int i = 0; i < niter; i += 2) {
-                if (i + 1 < niter) issue(i + 1, rgb, rab, nb, pvb);
-                stage(i, rga, raa, na, pva);
-                p8_barrier();
-                if (i + 1 < niter) {
-                    if (i + 2 < niter) issue(i + 2, rga, raa, na, pva);
-                    stage(i + 1, rgb, rab, nb, pvb);
-                    p8_barrier();
-                }
-            }
-        } else {
-            // K > 128: two register sets of g and a (16 KG registers) do not fit beside the coefficients -- ONE set, the
-            // next item requested right behind the staging: its latency overlaps the barrier wait (the consumers' MFMA
-            // loop is the longer phase at these K)
-            for (int i = 0; i < niter; ++i) {
-                stage(i, rga, raa, na, pva);
-                if (i + 1 < niter) issue(i + 1, rga, raa, na, pva);
-                p8_barrier();
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------- consumers
-    const int q = lane >> 4, r = lane & 15;
-    const int mtiles = (M + 15) / 16;
-    const __bf16* wq = reinterpret_cast<const __bf16*>(A.wp + (size_t)mtiles * kg16 * 256);
-    const size_t plane = (size_t)mtiles * kg32 * 512;
-    const int tr_off = (8 * q + (r >> 2)) * P6_LD + 4 * (r & 3);
-    const bool resident = (RD == KG) && A.mblocks == 1;
-    bf16x8 ah[TPW][RD], am[TPW][RD], al[TPW][RD];
-    const __bf16* wa[TPW];
-    bool tok[TPW];
-    int mt[TPW];
-    auto set_tiles = [&](int mb) {
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-            const int t = wave + 8 * j;
-            tok[j] = t < A.mt_run && mb * A.mt_run + t < mtiles;
-            mt[j] = min(mb * A.mt_run + t, mtiles - 1);
-            wa[j] = wq + ((size_t)mt[j] * kg32 * 64 + lane) * 8;
-        }
-    };
-    auto fetch_a = [&](int j, int s, bf16x8& h, bf16x8& m, bf16x8& l) {
-        const int sc = min(s, kg32 - 1);
-        h = *reinterpret_cast<const bf16x8*>(wa[j] + (size_t)sc * 512);
-        m = *reinterpret_cast<const bf16x8*>(wa[j] + (size_t)sc * 512 + plane);
-        l = *reinterpret_cast<const bf16x8*>(wa[j] + (size_t)sc * 512 + 2 * plane);
-    };
-    auto tr_frag = [&](const __bf16* pln, int s, int h2) -> bf16x8 {
-        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-        const __bf16* p0 = pln + 32 * s * P6_LD + tr_off + 16 * h2;
-        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
-        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * P6_LD));
-        return cat8_(v0, v1);
-    };
-    const bool has_add = A.addend != nullptr;
-    const bool add_s2 = has_add && A.addend_stride == 2;
-    const long long addP = add_s2 ? (long long)A.T * A.Ho * A.Wo : (long long)P;
-    int cur_mb = -1;
-    for (int i = 0; i < niter; ++i) {
-        const int it = (int)blockIdx.x + i * G;
-        const int mb = it / VT8;
-        const int vt0 = it - mb * VT8;
-        const bool valid = vt0 < VT;
-        const int vt = min(vt0, VT - 1);
-        const int n = vt / A.tiles, tile = vt - n * A.tiles;
-        const int pt0 = tile * P6_BN;
-        if (!resident || i == 0) {
-            if (mb != cur_mb) { set_tiles(mb); cur_mb = mb; }
-#pragma unroll
-            for (int j = 0; j < TPW; ++j)
-#pragma unroll
-                for (int s = 0; s < RD; ++s) fetch_a(j, s, ah[j][s], am[j][s], al[j][s]);
-        }
-        // ---- epilogue operands of this item (lane (q, r): rows 4 q + e of a tile, voxels 2 r, 2 r + 1), requested now
-        const int pl = pt0 + 2 * r;
-        const bool pv = valid && pl < P;              // P even: both voxels or none
-        const int pc2 = pv ? pl : 0;
-        int aoff[2] = {pc2, pc2 + 1};
-        bool av[2] = {has_add && pv, has_add && pv};
-        if (add_s2) {
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2) {
-                const int p = pc2 + j2;
-                const int hw = A.H * A.W;
-                const int t = p / hw, rem = p - t * hw;
-                const int h = rem / A.W, w = rem - h * A.W;
-                const bool even = !(h & 1) && !(w & 1);
-                av[j2] = av[j2] && even;
-                aoff[j2] = even ? (t * A.Ho + (h >> 1)) * A.Wo + (w >> 1) : 0;
-            }
-        }
-        float xv[TPW][4][2], mk[TPW][4][2], adv[TPW][4][2], esc[TPW][4], esh[TPW][4];
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = mt[j] * 16 + 4 * q + e;
-                const size_t mrow = (size_t)n * M + (m < M ? m : 0);
-                if (EPI == P7_ACTBWD) {
-                    const float2 c2 = *reinterpret_cast<const float2*>(A.ecoef + mrow * 2);
-                    esc[j][e] = c2.x; esh[j][e] = c2.y;
-                }
-                if (EPI != P7_PLAIN) {
-                    const float2 t2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(A.ex) + mrow * (size_t)P + pc2);
-                    xv[j][e][0] = t2.x; xv[j][e][1] = t2.y;
-                }
-                if (EPI == P7_RESBWD) {
-                    const float2 t2 = *reinterpret_cast<const float2*>(A.emask + mrow * (size_t)P + pc2);
-                    mk[j][e][0] = t2.x; mk[j][e][1] = t2.y;
-                }
-                if (has_add) {
-                    const float* pa = A.addend + mrow * (size_t)addP;
-                    if (!add_s2) {
-                        const float2 t2 = *reinterpret_cast<const float2*>(pa + pc2);
-                        adv[j][e][0] = t2.x; adv[j][e][1] = t2.y;
-                    } else {
-                        adv[j][e][0] = pa[aoff[0]]; adv[j][e][1] = pa[aoff[1]];
-                    }
-                }
-            }
-        }
-        p8_barrier();                                             // barrier i: buffer i & 1 is full
-        const __bf16* Dh = lds6 + (size_t)(i & 1) * bufsz;
-        const __bf16* Dm = Dh + (size_t)Kp * P6_LD;
-        const __bf16* Dl = Dm + (size_t)Kp * P6_LD;
-        f32x4 acc[TPW][2];
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        if (tok[0]) {
-#pragma unroll
-            for (int s = 0; s < KG; ++s) {
-                if (s < kg32) {
-                    const int slot = s % RD;
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const bf16x8 bh = tr_frag(Dh, s, h2), bm = tr_frag(Dm, s, h2), bl = tr_frag(Dl, s, h2);
-#pragma unroll
-                        for (int j = 0; j < TPW; ++j) {
-                            if (j == 0 || tok[j]) {                  // smallest terms first, as pw7_kernel<.., 3>
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j][slot], bh, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bl, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j][slot], bm, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j][slot], bh, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bm, acc[j][h2], 0, 0, 0);
-                                acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j][slot], bh, acc[j][h2], 0, 0, 0);
-                            }
-                        }
-                    }
-                    if (RD < KG && s + RD < kg32) {
-#pragma unroll
-                        for (int j = 0; j < TPW; ++j) fetch_a(j, s + RD, ah[j][slot], am[j][slot], al[j][slot]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                if (j == 0 || tok[j]) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int m = mt[j] * 16 + 4 * q + e;
-                        const bool mv = m < M;
-                        float v[2] = {acc[j][0][e], acc[j][1][e]};
-                        float s1 = 0.f, s2 = 0.f;
-                        if (has_add) { v[0] += av[0] ? adv[j][e][0] : 0.f; v[1] += av[1] ? adv[j][e][1] : 0.f; }
-                        if (EPI != P7_PLAIN) {
-#pragma unroll
-                            for (int j2 = 0; j2 < 2; ++j2) {
-                                const float xj = pv ? xv[j][e][j2] : 0.f;
-                                if (EPI == P7_RESBWD) v[j2] = (pv && mk[j][e][j2] > 0.f) ? v[j2] : 0.f;
-                                else v[j2] = pv ? v[j2] * act_bwd(fmaf(esc[j][e], xj, esh[j][e]), A.e_act) : 0.f;
-                                s1 += v[j2];
-                                s2 = fmaf(v[j2], xj, s2);
-                            }
-                        }
-                        if (mv && pv) *reinterpret_cast<float2*>(reinterpret_cast<float*>(A.y) + ((size_t)n * M + m) * (size_t)P + pl) = make_float2(v[0], v[1]);
-                        if (EPI != P7_PLAIN && A.partial != nullptr) {
-                            s1 = row16_sum(s1);
-                            s2 = row16_sum(s2);
-                            if (r == 0 && mv && valid) {
-                                float* pp = A.partial + (((size_t)n * M + m) * A.tiles + tile) * 2;
-                                pp[0] = s1; pp[1] = s2;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
+// (Round 4 also built pw9_kernel, the persistent producer / consumer form of pw7_kernel -- bitwise the same dX, measured at
+// 23-33 us against 23-26 us for pw7 at the stage 3-4 shapes and -1.5 ... -2.5 % on the step (profiles/r04/c_mb_*.txt,
+// d_sweep_*.txt): the epilogue operands of the data gradient cost the registers its resident A fragments need, and a
+// workgroup's phases do not overlap better than two co-resident pw7 workgroups do.  Removed again; git history has it.)
 
 }  // namespace
 
@@ -1121,51 +1114,35 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
     const int ns = x3d_opt(X3D_OPT_BWD_TERMS) == 2 ? 2 : 3;
     const size_t lds = (size_t)ns * kp * P6_LD * sizeof(__bf16);
     const int npass = cdiv(kp, P6_RP);
-    // round 4: the persistent producer / consumer form (three-term operands, fp32 storage, K <= 224)
-    if (!ga_bf && !y_bf && !ex_bf && ns == 3 && kp <= x3d_opt(X3D_OPT_PW9_MAX_K) && !x3d_opt(X3D_OPT_NO_PW8)) {
-        const int tpw = mtiles <= 8 ? 1 : 2;
-        A.mblocks = cdiv(mtiles, 8 * tpw);
-        A.mt_run = cdiv(mtiles, A.mblocks);
-        const int vt8 = (VT + 7) & ~7;
-        const int items = vt8 * A.mblocks;
-        int g = x3d_opt(X3D_OPT_PW8_GRID);
-        if (g <= 0) g = x3d_cu_count();
-        if (g > items) g = items;
-        const size_t lds9 = (size_t)2 * 3 * kp * P6_LD * sizeof(__bf16);
-        const int kg = kp / 32;
-#define P9_GO(EPI_, KG_, TPW_)                                                                                      \
+    // ADD2 (the stride-2 addend walk): its own instantiation on the default path (fp32 storage, three terms); the mixed-storage
+    // and two-term builds always carry it
+    const bool add2 = addend != nullptr && addend_stride == 2;
+#define P7_GO3(EPI_, NP, MX_, NS_, A2_)                                                                             \
     do {                                                                                                            \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw9_kernel<EPI_, KG_, TPW_>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 32 * KG_ * P6_LD * 2);     \
-            attr_done = true;                                                                                       \
-        }                                                                                                           \
-        hipLaunchKernelGGL((pw9_kernel<EPI_, KG_, TPW_>), dim3(g), dim3(P8_NT), lds9, s, A);                         \
-    } while (0)
-#define P9_KG(EPI_, TPW_)                                                                                           \
-    do {                                                                                                            \
-        if (kg <= 3) P9_GO(EPI_, 3, TPW_); else if (kg <= 4) P9_GO(EPI_, 4, TPW_);                                   \
-        else if (kg <= 6) P9_GO(EPI_, 6, TPW_); else P9_GO(EPI_, 7, TPW_);                                           \
-    } while (0)
-#define P9_EPI(EPI_) do { if (tpw == 1) P9_KG(EPI_, 1); else P9_KG(EPI_, 2); } while (0)
-        x3d_note_kernel("pw9_kernel");
-        if (mode == P7_PLAIN) P9_EPI(P7_PLAIN); else if (mode == P7_ACTBWD) P9_EPI(P7_ACTBWD); else P9_EPI(P7_RESBWD);
-#undef P9_EPI
-#undef P9_KG
-#undef P9_GO
-        X3D_LAUNCH_CHECK();
-        return X3D_OK;
-    }
-#define P7_GO2(EPI_, NP, MX_, NS_)                                                                                  \
-    do {                                                                                                            \
-        static bool attr_done = false;                                                                              \
-        if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP, MX_, NS_>),                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP, MX_, NS_, 8, A2_>),        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, NS_ * P6_RP * NP * P6_LD * 2);     \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL((pw7_kernel<EPI_, NP, MX_, NS_>), grid, block, lds, s, A);                                \
+        hipLaunchKernelGGL((pw7_kernel<EPI_, NP, MX_, NS_, 8, A2_>), grid, block, lds, s, A);                        \
+    } while (0)
+#define P7_GOR(NP, MX_, NS_)                                                                                        \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7r_kernel<P7_RESBWD, NP, MX_, NS_>),          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, NS_ * P6_RP * NP * P6_LD * 2);     \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((pw7r_kernel<P7_RESBWD, NP, MX_, NS_>), grid, block, lds, s, A);                          \
+    } while (0)
+#define P7_GO2(EPI_, NP, MX_, NS_)                                                                                  \
+    do {                                                                                                            \
+        if (EPI_ == P7_RESBWD) P7_GOR(NP, MX_, NS_);                                                                 \
+        else if (MX_ || NS_ == 2) P7_GO3(EPI_, NP, MX_, NS_, true);                                                  \
+        else if (add2) P7_GO3(EPI_, NP, false, 3, true);                                                             \
+        else P7_GO3(EPI_, NP, false, 3, false);                                                                      \
     } while (0)
 #define P7_GO(EPI_, NP, MX_) do { if (ns == 2) P7_GO2(EPI_, NP, MX_, 2); else P7_GO2(EPI_, NP, MX_, 3); } while (0)
 #define P7_PASS(EPI_, MX_)                                                                                           \
@@ -1182,17 +1159,35 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
     do {                                                                                                            \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP, false, 3, 16>),            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP, false, 3, 16, true>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * NP * P6_LD * 2);         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7_kernel<EPI_, NP, false, 3, 16, false>),     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * NP * P6_LD * 2);         \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL((pw7_kernel<EPI_, NP, false, 3, 16>), grid16, dim3(1024), lds, s, A);                     \
+        if (addend != nullptr && addend_stride == 2)                                                                \
+            hipLaunchKernelGGL((pw7_kernel<EPI_, NP, false, 3, 16, true>), grid16, dim3(1024), lds, s, A);           \
+        else                                                                                                        \
+            hipLaunchKernelGGL((pw7_kernel<EPI_, NP, false, 3, 16, false>), grid16, dim3(1024), lds, s, A);          \
+    } while (0)
+#define P7_GOR16(NP)                                                                                                \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw7r_kernel<P7_RESBWD, NP, false, 3, 16>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * NP * P6_LD * 2);         \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((pw7r_kernel<P7_RESBWD, NP, false, 3, 16>), grid16, dim3(1024), lds, s, A);               \
     } while (0)
 #define P7_NP16(EPI_) do { if (kp <= 128) P7_GO16(EPI_, 1); else if (kp <= 256) P7_GO16(EPI_, 2); else P7_GO16(EPI_, 4); } while (0)
         x3d_note_kernel("pw7_kernel");
-        if (mode == P7_PLAIN) P7_NP16(P7_PLAIN); else if (mode == P7_ACTBWD) P7_NP16(P7_ACTBWD); else P7_NP16(P7_RESBWD);
+        if (mode == P7_PLAIN) P7_NP16(P7_PLAIN);
+        else if (mode == P7_ACTBWD) P7_NP16(P7_ACTBWD);
+        else { if (kp <= 128) P7_GOR16(1); else if (kp <= 256) P7_GOR16(2); else P7_GOR16(4); }
 #undef P7_NP16
 #undef P7_GO16
+#undef P7_GOR16
         X3D_LAUNCH_CHECK();
         return X3D_OK;
     }
@@ -1205,6 +1200,8 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
 #undef P7_PASS
 #undef P7_GO
 #undef P7_GO2
+#undef P7_GO3
+#undef P7_GOR
     X3D_LAUNCH_CHECK();
     return X3D_OK;
 }

@@ -348,9 +348,10 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
                     const bf16x8 am = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * WP + 1) * 64 + lane) * 8]);
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
-                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[h2], dacc[j][h2], 0, 0, 0);
-                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[h2], dacc[j][h2], 0, 0, 0);
-                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[h2], dacc[j][h2], 0, 0, 0);
+                        // (round 4: dY fragment as the A operand -> transposed accumulator tile, see the epilogue)
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[h2], am, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[h2], ah, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[h2], ah, dacc[j][h2], 0, 0, 0);
                     }
                 }
             } else {
@@ -367,80 +368,97 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
                         bf16x8 al;
                         if (WP == 3) al = *reinterpret_cast<const bf16x8*>(&Wl[(((mtl_ * KS + s) * WP + 2) * 64 + lane) * 8]);
                         else al = alo[(WP < NS) ? j : 0][(WP < NS) ? s : 0];
-                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, dacc[j][h2], 0, 0, 0);      // smallest terms first
-                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, dacc[j][h2], 0, 0, 0);
-                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, dacc[j][h2], 0, 0, 0);
-                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, dacc[j][h2], 0, 0, 0);
-                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, dacc[j][h2], 0, 0, 0);
-                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, dacc[j][h2], 0, 0, 0);      // smallest terms first
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah, dacc[j][h2], 0, 0, 0);
+                        dacc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, dacc[j][h2], 0, 0, 0);
                     }
                 }
             }
         }
     };
 
-    // epilogue of one chunk: lane owns rows 4 q + e of each unit and voxels 32 half + 2 r, + 1; operands from the raw LDS
-    // tiles (the chunk's tail columns hold clamped duplicates: masked by pv)
+    // epilogue of one chunk.  Round 4: the data-gradient accumulators are TRANSPOSED tiles (dY fragment = MFMA A operand): lane
+    // (q, r) owns input channel lt * 16 + r and the 8 consecutive voxels 32 half + 8 q + jj = dacc[.][jj & 1][jj >> 1]
+    // (voxel v of a half sits at LDS column (v & 1) * 16 + (v >> 1)) -- operands come out of the raw LDS tiles as two b128
+    // reads each, dX goes out as two 16-byte stores, the statistics need two cross-row steps instead of 8 DPP adds per row.
     auto epilogue = [&](int n, int tile) {
-        const int vl = 32 * half + 2 * r;                     // voxel within the chunk
-        const int pl = tile * F_PT + vl;
-        const bool pv = pl < P;                               // P even: both voxels or none
+        const int vl = 32 * half + 8 * q;                     // first voxel within the chunk
+        const int p0 = tile * F_PT + vl;
+        const bool pva = p0 < P, pvb = p0 + 4 < P;            // P % 4 == 0: whole groups of four (clamped duplicates masked)
         char* dxs = mx_base(A.dx, (size_t)n * Ci * (size_t)P, DX_BF);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int lt = mpar + MP * j;
             if (lt * 16 >= CI) continue;                      // wave-uniform: this unit does not exist (16-wave variants)
+            const int ml = lt * 16 + r;
+            const bool mv = ml < Ci;
+            const int mr = CR < CI ? min(ml, CR - 1) : ml;    // raw-tile row (rows >= Ci are masked by mv)
+            float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ml = lt * 16 + 4 * q + e;
-                const bool mv = ml < Ci;
-                float v[2] = {dacc[j][0][e], dacc[j][1][e]};
-                float s1 = 0.f, s2 = 0.f;
+            for (int jj = 0; jj < 8; ++jj) v[jj] = dacc[j][jj & 1][jj >> 1];
+            if (ADD) {
+                const float4 a0 = *reinterpret_cast<const float4*>(&Ar[mr * F_RL + vl]);
+                const float4 a1 = *reinterpret_cast<const float4*>(&Ar[mr * F_RL + vl + 4]);
+                v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+            }
+            float s1 = 0.f, s2 = 0.f;
+            if (EPI != FE_PLAIN) {
+                float xa[8], ea[8];
                 float esc = 1.f, esh = 0.f;
-                if (EPI == FE_ACTBWD) {                       // no global load here: it would queue behind the prefetch (vmcnt is in order)
-                    const float2 c2 = Cf[ml];
-                    esc = c2.x; esh = c2.y;
-                }
-                const int mr = CR < CI ? min(ml, CR - 1) : ml;       // raw-tile row (rows >= Ci are masked by mv)
-                if (ADD) {
-                    const float2 a2 = *reinterpret_cast<const float2*>(&Ar[mr * F_RL + vl]);
-                    v[0] += pv ? a2.x : 0.f; v[1] += pv ? a2.y : 0.f;
-                }
-                if (EPI != FE_PLAIN) {
-                    float2 x2, e2 = make_float2(0.f, 0.f);
-                    if (EPI == FE_RESBWD) {
-                        // the ReLU mask of the producing block: sign of x from the hi plane of the staged X image (the
-                        // conv's input IS that block's output; voxels 2 r, 2 r + 1 of the half sit at columns r, r + 16)
-                        x2 = make_float2((float)Xh[ml * F_LD + 32 * half + r], (float)Xh[ml * F_LD + 32 * half + r + 16]);
-                        e2 = *reinterpret_cast<const float2*>(&Er[mr * F_RL + vl]);
-                    } else {
-                        x2 = *reinterpret_cast<const float2*>(&Xr[mr * F_RL + vl]);
-                    }
-                    const float xa[2] = {x2.x, x2.y}, ea[2] = {e2.x, e2.y};
+                if (EPI == FE_RESBWD) {
+                    // ReLU mask of the producing block: sign of x from the hi plane of the staged X image (even voxels of
+                    // the half at columns 4 q .. 4 q + 3, odd ones 16 further)
+                    const bf16x4 xe = *reinterpret_cast<const bf16x4*>(&Xh[ml * F_LD + 32 * half + 4 * q]);
+                    const bf16x4 xo = *reinterpret_cast<const bf16x4*>(&Xh[ml * F_LD + 32 * half + 4 * q + 16]);
 #pragma unroll
-                    for (int j2 = 0; j2 < 2; ++j2) {
-                        const float xj = pv ? xa[j2] : 0.f;
-                        float mul;                                   // statistics multiplier
-                        if (EPI == FE_RESBWD) {
-                            v[j2] = (pv && xj > 0.f) ? v[j2] : 0.f;
-                            mul = pv ? ea[j2] : 0.f;
-                        } else {
-                            v[j2] = pv ? v[j2] * act_bwd(fmaf(esc, xj, esh), A.xact) : 0.f;
-                            mul = xj;
-                        }
-                        v[j2] = stored(v[j2], DX_BF);
-                        s1 += v[j2];
-                        s2 = fmaf(v[j2], mul, s2);
-                    }
+                    for (int i2 = 0; i2 < 4; ++i2) { xa[2 * i2] = (float)xe[i2]; xa[2 * i2 + 1] = (float)xo[i2]; }
+                    const float4 e0 = *reinterpret_cast<const float4*>(&Er[mr * F_RL + vl]);
+                    const float4 e1 = *reinterpret_cast<const float4*>(&Er[mr * F_RL + vl + 4]);
+                    ea[0] = e0.x; ea[1] = e0.y; ea[2] = e0.z; ea[3] = e0.w; ea[4] = e1.x; ea[5] = e1.y; ea[6] = e1.z; ea[7] = e1.w;
+                } else {
+                    const float2 c2 = Cf[ml];                 // no global load here: it would queue behind the prefetch
+                    esc = c2.x; esh = c2.y;
+                    const float4 x0 = *reinterpret_cast<const float4*>(&Xr[mr * F_RL + vl]);
+                    const float4 x1 = *reinterpret_cast<const float4*>(&Xr[mr * F_RL + vl + 4]);
+                    xa[0] = x0.x; xa[1] = x0.y; xa[2] = x0.z; xa[3] = x0.w; xa[4] = x1.x; xa[5] = x1.y; xa[6] = x1.z; xa[7] = x1.w;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) ea[jj] = 0.f;
                 }
-                if (mv && pv) sto2(dxs, (unsigned)ml * (unsigned)P + (unsigned)pl, DX_BF, v[0], v[1]);
-                if (EPI != FE_PLAIN) {
-                    s1 = row16_sum(s1);
-                    s2 = row16_sum(s2);
-                    if (r == 0) {
-                        red[((wave * U + j) * 16 + 4 * q + e) * 2] = mv ? s1 : 0.f;
-                        red[((wave * U + j) * 16 + 4 * q + e) * 2 + 1] = mv ? s2 : 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const bool pj = (jj < 4) ? pva : pvb;
+                    const float xj = pj ? xa[jj] : 0.f;
+                    float mul;                                   // statistics multiplier
+                    if (EPI == FE_RESBWD) {
+                        v[jj] = (pj && xj > 0.f) ? v[jj] : 0.f;
+                        mul = pj ? ea[jj] : 0.f;
+                    } else {
+                        v[jj] = pj ? v[jj] * act_bwd(fmaf(esc, xj, esh), A.xact) : 0.f;
+                        mul = xj;
                     }
+                    v[jj] = stored(v[jj], DX_BF);
+                    s1 += v[jj];
+                    s2 = fmaf(v[jj], mul, s2);
+                }
+            }
+            const unsigned yo = (unsigned)(mv ? ml : 0) * (unsigned)P + (unsigned)p0;
+            if (mv && pva) {
+                if (DX_BF) { sto2(dxs, yo, 1, v[0], v[1]); sto2(dxs, yo + 2, 1, v[2], v[3]); }
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(dxs) + yo) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (mv && pvb) {
+                if (DX_BF) { sto2(dxs, yo + 4, 1, v[4], v[5]); sto2(dxs, yo + 6, 1, v[6], v[7]); }
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(dxs) + yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (EPI != FE_PLAIN) {
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (q == 0) {
+                    red[((wave * U + j) * 16 + r) * 2] = mv ? s1 : 0.f;
+                    red[((wave * U + j) * 16 + r) * 2 + 1] = mv ? s2 : 0.f;
                 }
             }
         }
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
         fetch(n, tile * F_PT);
         for (;;) {
             store(tile * F_PT);
-            __syncthreads();                 // chunk staged
+            x3d_lds_barrier();               // chunk staged (LDS only: round 4)
             const int cn = c + G;
             const bool more = cn < total;
             const int nn = more ? cn / cps : n, ntile = more ? cn - nn * cps : tile;
@@ -474,7 +492,7 @@ __global__ __launch_bounds__(64 * NWV, OCC) void pw_bwd_fused_kernel(const FbArg
             compute_w();
             compute_d();
             epilogue(n, tile);
-            __syncthreads();                 // everyone done reading this chunk's images; red[] complete
+            x3d_lds_barrier();               // everyone done reading this chunk's images; red[] complete
             if (EPI != FE_PLAIN) write_stats(n, tile);
             if (!more) break;
             c = cn; n = nn; tile = ntile;
@@ -622,47 +640,58 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(wb + 2 * 64 * 8);
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
-                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[h2], acc[j][h2], 0, 0, 0);
-                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[h2], acc[j][h2], 0, 0, 0);
-                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[h2], acc[j][h2], 0, 0, 0);
-                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[h2], acc[j][h2], 0, 0, 0);
-                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[h2], acc[j][h2], 0, 0, 0);
-                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[h2], acc[j][h2], 0, 0, 0);
+                    // round 4: activation fragment as the A operand -> TRANSPOSED accumulator tile (pw6.hip has the argument):
+                    // lane (q, r) owns channel lt * 16 + r and 8 consecutive voxels
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[h2], al, acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[h2], ah, acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[h2], am, acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[h2], am, acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[h2], ah, acc[j][h2], 0, 0, 0);
+                    acc[j][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[h2], ah, acc[j][h2], 0, 0, 0);
                 }
             }
         }
     };
-    // BN statistics of this workgroup's chunks of ONE sample, accumulated in registers (every lane of a 16-lane row group
-    // holds its rows' sums) and written as one partial per (sample, row, workgroup) when the range leaves the sample
-    float sa[U][4][2];
+    // BN statistics of this workgroup's chunks of ONE sample, accumulated in registers: every lane sums ITS channel over ITS
+    // voxels (no cross-lane step per chunk); the four lane groups of a channel are combined when the range leaves the sample
+    float sa[U][2];
 #pragma unroll
-    for (int j = 0; j < U; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sa[j][e][0] = 0.f; sa[j][e][1] = 0.f; }
+    for (int j = 0; j < U; ++j) { sa[j][0] = 0.f; sa[j][1] = 0.f; }
     auto epilogue = [&](int c, bool flush) {
         const int n = c / cps, tile = c - n * cps;
-        const int pl = tile * F_PT + 32 * half + 2 * r;
-        const bool pv = pl < P;
+        const int p0 = tile * F_PT + 32 * half + 8 * q;              // 8 consecutive voxels: acc[.][jj & 1][jj >> 1]
+        const bool pva = p0 < P, pvb = p0 + 4 < P;                   // P % 4 == 0: whole groups of four
         char* ys = mx_base(A.y, (size_t)n * M * (size_t)P, y_bf);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int lt = mpar + MPW * j;
             if (lt * 16 >= MP) continue;
+            const int ml = lt * 16 + r;
+            const bool mv = ml < M;
+            float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ml = lt * 16 + 4 * q + e;
-                const bool mv = ml < M;
-                const float v0 = stored(pv ? acc[j][0][e] : 0.f, y_bf), v1 = stored(pv ? acc[j][1][e] : 0.f, y_bf);
-                if (mv && pv) sto2(ys, (unsigned)ml * (unsigned)P + (unsigned)pl, y_bf, v0, v1);
-                sa[j][e][0] += row16_sum(v0 + v1);
-                sa[j][e][1] += row16_sum(fmaf(v0, v0, v1 * v1));
-                if (flush) {
-                    if (r == 0) {
-                        red[((wave * U + j) * 16 + 4 * q + e) * 2] = mv ? sa[j][e][0] : 0.f;
-                        red[((wave * U + j) * 16 + 4 * q + e) * 2 + 1] = mv ? sa[j][e][1] : 0.f;
-                    }
-                    sa[j][e][0] = 0.f; sa[j][e][1] = 0.f;
+            for (int jj = 0; jj < 8; ++jj) v[jj] = stored(((jj < 4) ? pva : pvb) ? acc[j][jj & 1][jj >> 1] : 0.f, y_bf);
+            const unsigned yo = (unsigned)(mv ? ml : 0) * (unsigned)P + (unsigned)p0;
+            if (mv && pva) {
+                if (y_bf) { sto2(ys, yo, 1, v[0], v[1]); sto2(ys, yo + 2, 1, v[2], v[3]); }
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ys) + yo) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (mv && pvb) {
+                if (y_bf) { sto2(ys, yo + 4, 1, v[4], v[5]); sto2(ys, yo + 6, 1, v[6], v[7]); }
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ys) + yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            sa[j][0] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            sa[j][1] += (fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3])) +
+                        (fmaf(v[4], v[4], v[5] * v[5]) + fmaf(v[6], v[6], v[7] * v[7]));
+            if (flush) {
+                float s1 = sa[j][0], s2 = sa[j][1];
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (q == 0) {
+                    red[((wave * U + j) * 16 + r) * 2] = mv ? s1 : 0.f;
+                    red[((wave * U + j) * 16 + r) * 2 + 1] = mv ? s2 : 0.f;
                 }
+                sa[j][0] = 0.f; sa[j][1] = 0.f;
             }
         }
     };
@@ -692,12 +721,12 @@ __global__ __launch_bounds__(64 * NWV, 4) void pw_fwd_stream_kernel(const FsArgs
         if (c_begin + 1 < c_end) fetch(c_begin + 1, rxb, cfb);
         auto iter = [&](int c, float4 (&rcur)[NX], float2 (&ccur)[NX]) {
             store(c, rcur, ccur);
-            __syncthreads();                 // chunk staged
+            x3d_lds_barrier();               // chunk staged (LDS only: round 4)
             if (c + 2 < c_end) fetch(c + 2, rcur, ccur);     // two chunks ahead, into the set just consumed
             compute();
             const bool flush = (c + 1 == c_end) || ((c + 1) / cps != c / cps);
             epilogue(c, flush && A.partial != nullptr);
-            __syncthreads();                 // images free; red[] complete
+            x3d_lds_barrier();               // images free; red[] complete
             if (flush && A.partial != nullptr) write_stats(c / cps);
         };
         for (int c = c_begin; c < c_end; c += 2) {
