@@ -168,12 +168,12 @@ int x3d_pw_bwd_data_res(const void* g, const void* a, const float* cb, const flo
  *                                                             partial {sum out, sum out*ex}     (x3d_pw_bwd_data_res)
  * wpacked_t = the transposed pack of x3d_pw_pack (its split-bf16 planes are the data gradient's A operand).
  * wpartial is float[x3d_pw_bwd_fused_groups(N,P)][Cout][Cin] (x3d_reduce_partials sums it); partial is
- * float[N][Cin][x3d_pw_bwd_fused_tiles(P)][2].  x3d_pw_bwd_fused_ok tells whether (Cin, Cout, P, mode, addend) is in the kernel's set
+ * float[N][Cin][x3d_pw_bwd_fused_tiles(N,P)][2].  x3d_pw_bwd_fused_ok tells whether (Cin, Cout, P, mode, addend) is in the kernel's set
  * (dense, P % 4 == 0, both channel counts <= 128); other shapes use the separate entry points. */
 /* mx: 0; X3D_MX_GA (g, a bf16: any mode); X3D_MX_X | X3D_MX_Y (x and dx bf16: mode 1 without addend) */
 int x3d_pw_bwd_fused_ok(int Cin, int Cout, int P, int mode, int has_addend, int mx);
 int x3d_pw_bwd_fused_groups(int N, int P);
-int x3d_pw_bwd_fused_tiles(int P);
+int x3d_pw_bwd_fused_tiles(int N, int P);   /* (round 4: one slot per workgroup touching a sample, not per 64-voxel chunk) */
 int x3d_pw_bwd_fused(const void* g, const void* a, const float* cb, const float* wpacked_t, const void* x,
                      const float* xpre, int xact, int mode, const float* ex, const float* addend, int addend_stride,
                      void* dx, float* wpartial, float* partial, int N, int Cin, int Cout, int T, int H, int W,

@@ -49,7 +49,7 @@ SIGNATURES = {
     "x3d_pw_bwd_data_res": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
     "x3d_pw_bwd_fused_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "x3d_pw_bwd_fused_groups": (_I, [_I, _I]),
-    "x3d_pw_bwd_fused_tiles": (_I, [_I]),
+    "x3d_pw_bwd_fused_tiles": (_I, [_I, _I]),
     "x3d_pw_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "x3d_pw_wgrad_groups": (_I, [_I, _I, _I, _I, _I]),
     "x3d_pw_bwd_weight": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -326,7 +326,7 @@ def pw_bwd_fused(g, a, cb, w_shape, wpt, x, xpre=None, xact=ACT_NONE, mode=0, ex
     mx = pw_bwd_fused_mx(g, x)
     dx = _f((N, Cin, T, H, W), g, x.dtype)          # the gradient of a bf16 tensor is stored as bf16
     wpartial = _f((groups, Cout * Cin), g)
-    partial = _f((N, Cin, L.x3d_pw_bwd_fused_tiles(P), 2), g) if mode != 0 else None
+    partial = _f((N, Cin, L.x3d_pw_bwd_fused_tiles(N, P), 2), g) if mode != 0 else None
     check(L.x3d_pw_bwd_fused(ptr(g), ptr(a), ptr(cb), ptr(wpt), ptr(x), ptr(xpre), xact, mode, ptr(ex), ptr(addend),
                              addend_stride, ptr(dx), ptr(wpartial), ptr(partial), N, Cin, Cout, T, H, W, mx,
                              _lib.stream()))
