@@ -41,9 +41,9 @@ def fam(name):
     template argument tells them apart (IN = 2 is the BN-backward prologue of the data gradient)."""
     if "pw_bwd_fused_kernel" in name:
         return "pw_bwd_fused"
-    if "pw6_kernel" in name or "pw_fwd_stream_kernel" in name:
+    if "pw6_kernel" in name or "pw8_kernel" in name or "pw_fwd_stream_kernel" in name:
         return "pw_fwd"
-    if "pw7_kernel" in name or "pw5_kernel" in name:
+    if "pw7_kernel" in name or "pw7r_kernel" in name or "pw5_kernel" in name:
         return "pw_bwd_data"
     m = re.search(r"pw4_kernel<(\d+)", name) or re.search(r"pw2_kernel<(\d+)", name)
     if m:

@@ -109,6 +109,11 @@ def lib():
         raise X3DHipError(
             "libx3dhip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C x3d-multigrid_amd/csrc`). The X3D product path has no fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64: import torch FIRST, so that the library's HIP dependency resolves to the runtime
+    # torch already loaded.  Loaded the other way round (this library before torch, e.g. `python __graft_entry__.py smoke`,
+    # which builds and then smokes in one process) the process holds two HIP runtimes and the library's launches fail with
+    # "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     h = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
