@@ -1181,7 +1181,7 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
         hipLaunchKernelGGL((pw7r_kernel<P7_RESBWD, NP, false, 3, 16>), grid16, dim3(1024), lds, s, A);               \
     } while (0)
 #define P7_NP16(EPI_) do { if (kp <= 128) P7_GO16(EPI_, 1); else if (kp <= 256) P7_GO16(EPI_, 2); else P7_GO16(EPI_, 4); } while (0)
-        x3d_note_kernel("pw7_kernel");
+        x3d_note_kernel(mode == P7_RESBWD ? "pw7r_kernel" : "pw7_kernel");
         if (mode == P7_PLAIN) P7_NP16(P7_PLAIN);
         else if (mode == P7_ACTBWD) P7_NP16(P7_ACTBWD);
         else { if (kp <= 128) P7_GOR16(1); else if (kp <= 256) P7_GOR16(2); else P7_GOR16(4); }
@@ -1191,7 +1191,7 @@ int x3d_pw7_launch(const void* g, const void* a, const float* cb, const float* w
         X3D_LAUNCH_CHECK();
         return X3D_OK;
     }
-    x3d_note_kernel("pw7_kernel");
+    x3d_note_kernel(mode == P7_RESBWD ? "pw7r_kernel" : "pw7_kernel");
     if (ga_bf || y_bf || ex_bf) {
         if (mode == P7_PLAIN) P7_PASS(P7_PLAIN, true); else if (mode == P7_ACTBWD) P7_PASS(P7_ACTBWD, true); else P7_PASS(P7_RESBWD, true);
     } else {
